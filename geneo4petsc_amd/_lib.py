@@ -1,0 +1,120 @@
+"""ctypes binding of libgeneopc.so (C ABI declared in include/geneo_c.h).
+
+The product path is HIP only: ``load()`` loads the in-tree ``libgeneopc.so`` and raises if it is
+missing or if it is not the gfx950 build.  There is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeneopc.so")
+
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+
+
+class GeneoCsr(C.Structure):
+    _fields_ = [("n", C.c_int), ("rowptr", c_int_p), ("col", c_int_p), ("val", c_dbl_p)]
+
+
+class GeneoIS(C.Structure):
+    _fields_ = [("n", C.c_int), ("idx", c_int_p)]
+
+
+class GeneoMatIS(C.Structure):
+    _fields_ = [("nbDOF", C.c_int), ("nbDOFLoc", C.c_int), ("map", c_int_p), ("local", GeneoCsr)]
+
+
+class GeneoInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("estimDimELoc", "realDimELoc", "nicolaidesLoc", "dimE",
+                                       "eig_iterations", "eig_spmm")] + \
+               [(n, C.c_longlong) for n in ("dls1_iterations", "dls1_solves", "spmv_calls")] + \
+               [(n, C.c_double) for n in ("lvl1SetupMinvTimeLoc", "lvl2SetupEigTimeLoc", "lvl2SetupZTimeLoc",
+                                          "lvl2SetupETimeLoc", "lvl1ApplyTimeLoc", "lvl1ApplyScatterTimeLoc",
+                                          "lvl1ApplyMinvTimeLoc", "lvl1ApplyGatherTimeLoc",
+                                          "lvl1ApplyPrjFSTimeLoc", "lvl2ApplyTimeLoc", "lvl2ApplyZtTimeLoc",
+                                          "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+# every symbol include/geneo_c.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "PCCreate_GenEO": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "createGenEOPC": (C.c_int, [C.c_void_p]),
+    "PCDestroy_GenEO": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "PCSetFromOptions_GenEO": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]),
+    "PCGenEOSetOption": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "PCGenEOGetName": (C.c_char_p, [C.c_void_p]),
+    "PCGenEOGetError": (C.c_char_p, [C.c_void_p]),
+    "usageGenEO_c": (C.c_char_p, []),
+    "PCSetOperators_GenEO": (C.c_int, [C.c_void_p, C.POINTER(GeneoMatIS)]),
+    "PCGenEOSetup": (C.c_int, [C.c_void_p, C.POINTER(GeneoCsr), GeneoIS, C.POINTER(GeneoIS)]),
+    "initGenEOPC_c": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, c_int_p, C.POINTER(GeneoCsr),
+                                C.POINTER(GeneoCsr), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]),
+    "PCGenEOSetSizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "PCGenEOAddSubdomain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(GeneoCsr),
+                                      C.POINTER(GeneoCsr)]),
+    "PCGenEOSetComm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p,
+                                 c_int_p, c_int_p, EXCHANGE_FN, ALLREDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int]),
+    "PCSetUp_GenEO": (C.c_int, [C.c_void_p]),
+    "PCApply_GenEO": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "PCGenEOApplyQ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "MatMult_GenEO": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "PCGenEOGetX0": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "PCGenEOSetRHS": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "KSPSolve_GenEO": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_dbl_p, c_int_p]),
+    "PCGenEOGetResidualHistory": (C.c_int, [C.c_void_p, c_dbl_p, C.c_int]),
+    "PCGenEOGetInfo": (C.c_int, [C.c_void_p, C.POINTER(GeneoInfo)]),
+    "PCGenEOGetEigenvalues": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, C.c_int]),
+    "PCGenEOGetCandidates": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, C.c_int]),
+    "PCGenEOGetE": (C.c_int, [C.c_void_p, c_dbl_p, C.c_int]),
+    "PCGenEOGetLocalDims": (C.c_int, [C.c_void_p, c_int_p, C.c_int]),
+    "GeneoBackendName": (C.c_char_p, []),
+    "GeneoSetStream": (C.c_int, [C.c_void_p]),
+    "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),
+    "GeneoDeviceFree": (None, [C.c_void_p]),
+    "GeneoH2D": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "GeneoD2H": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "GeneoDeviceSync": (C.c_int, []),
+    "GeneoSelfTestMFMA": (C.c_int, []),
+    "GeneoSetMFMA": (C.c_int, [C.c_int]),
+    "GeneoSpmvCreate": (C.c_int, [C.POINTER(GeneoCsr), C.POINTER(C.c_void_p)]),
+    "GeneoSpmvApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "GeneoSpmvTime": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),
+    "GeneoSpmvDestroy": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "GeneoSpmmApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "GeneoBlockKernel": (C.c_int, [C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p,
+                                   C.c_int, c_dbl_p]),
+}
+
+
+def bind(path):
+    """dlopen `path` and attach the prototypes of include/geneo_c.h.  Raises if a symbol is missing."""
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """The product library.  Fails loudly when the HIP build is absent -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libgeneopc.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = bind(LIB_PATH)
+    backend = lib.GeneoBackendName().decode()
+    if backend != "hip-gfx950":
+        raise RuntimeError("libgeneopc.so was not built with the HIP backend (got %r)" % backend)
+    _lib = lib
+    return lib

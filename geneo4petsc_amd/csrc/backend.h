@@ -1,0 +1,130 @@
+// Device-primitive interface of libgeneopc.
+//
+// The GenEO core (core.cpp) is written once against these primitives.  The PRODUCT library
+// links exactly one implementation: backend_hip.hip (hand-written gfx950 kernels).  There is no
+// CPU implementation inside the product.  tests/hostsim/backend_host.cpp implements the same
+// interface with serial loops and is linked ONLY into a test-side library used by the CPU
+// (`-m "not gpu"`) host-logic tests; it is never built by, shipped with, or loaded from the
+// geneo4petsc_amd package.
+//
+// All pointers are device pointers unless named h_*.  All operations are ordered on the single
+// stream set with bk::set_stream (default: the null stream).  FP64 values, 32-bit indices.
+// Tall-skinny blocks are row-major with an explicit leading dimension (ld >= #columns).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace bk {
+
+const char* name();                       // "hip-gfx950" | "hostsim"
+void set_stream(void* hip_stream);        // stream used for every launch / async copy
+void* get_stream();
+void sync();                              // wait for the stream
+
+void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
+void  dfree(void* p);
+void  h2d(void* d, const void* h, size_t bytes);
+void  d2h(void* h, const void* d, size_t bytes);   // synchronous w.r.t. the stream
+void  d2d(void* dst, const void* src, size_t bytes);
+void  zero(void* d, size_t bytes);
+
+// ---- CSR -----------------------------------------------------------------------------------
+struct Csr {
+  int n = 0;              // rows
+  int64_t nnz = 0;
+  int* rowptr = nullptr;  // n+1
+  int* col = nullptr;     // nnz
+  double* val = nullptr;  // nnz
+  int* rowblk = nullptr;  // nblk+1 : first row of each LDS row block
+  int nblk = 0;
+  int max_row = 0;
+};
+Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
+void csr_free(Csr& a);
+void spmv(const Csr& a, const double* x, double* y);                    // y = A x
+// Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
+void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                  const double* post);
+void csr_diag(const Csr& a, double* diag);
+
+// ---- index kernels -------------------------------------------------------------------------
+void gather(double* out, const double* in, const int* idx, int n);                       // out[i]=in[idx[i]]
+void gather_mul(double* out, const double* in, const int* idx, const double* d, int n);  // ... * d[i]
+// out[e] (+)= sum_{k in [ptr[e],ptr[e+1])} in[idx[k]]   (fixed order)
+void segsum(double* out, const double* in, const int* ptr, const int* idx, int nseg, bool accumulate);
+
+// ---- BLAS-1 --------------------------------------------------------------------------------
+void set(double* x, double v, int n);
+void copy(double* y, const double* x, int n);
+void axpy(double* y, double a, const double* x, int n);             // y += a x
+void axpby(double* y, double a, const double* x, double b, int n);  // y = a x + b y
+void xmy(double* y, const double* x, const double* d, int n);       // y = x .* d
+void axpy_dev(double* y, const double* a_dev, double sign, const double* x, int n);  // y += sign*a[0]*x
+void dot(const double* x, const double* y, int n, double* out_dev);  // deterministic
+
+// ---- chunked (per-subdomain) kernels on the concatenated local space ------------------------
+// The local space L is the concatenation of the rank's subdomains, cut into chunks of at most
+// CHUNK entries that never straddle two subdomains.  One workgroup handles one chunk.
+constexpr int CHUNK = 1024;
+struct Chunks {
+  int nchunk = 0, nsub = 0, n = 0;
+  int* start = nullptr;    // nchunk
+  int* len = nullptr;      // nchunk
+  int* sub = nullptr;      // nchunk
+  int* subptr = nullptr;   // nsub+1 : first chunk of each subdomain
+  int* suboff = nullptr;   // nsub+1 : first row of each subdomain
+  double* partial = nullptr;  // 4*nchunk scratch
+};
+Chunks chunks_upload(int nsub, const int* h_suboff /*nsub+1*/);
+void   chunks_free(Chunks& c);
+// out[s*stride + slot] = sum over subdomain s of x.*y
+void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot);
+
+// Batched Jacobi-PCG: one independent CG per subdomain, scalars in sc[s*8+k]:
+//   0 rz(parity 0) 1 rz(parity 1) 2 pAp 3 rr 4 alpha 5 beta 6 active(0/1) 7 rr0
+void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, double* p, const double* b,
+              const double* dinv);                                       // x=0 r=b z=dinv.*r p=z
+void seg_pap(const Chunks& c, const double* p, const double* q);         // chunk partials of p.q
+void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, double* z, const double* p,
+               const double* q, const double* dinv);                     // alpha; x,r,z; partials
+void cg_direction(const Chunks& c, double* sc, int parity, double* p, const double* z, double tol2);
+
+// ---- tall-skinny block kernels, per subdomain -----------------------------------------------
+// G[s] (p x q row-major at G + s*p*q) = S_s^T T_s
+void gram(const Chunks& c, const double* S, int lds, int p, const double* T, int ldt, int q, double* G);
+// Y_s (+)= S_s C_s : S (n x p), C[s] (p x q row-major at C + s*p*q), Y (n x q)
+void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C, int q, double* Y, int ldy,
+               bool accumulate);
+// R = AX - BX diag(lam_s) ; nrm[s*m+j] = ||R_j||_2^2 over subdomain s ; lam[s*m+j]
+void block_residual(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
+                    int m, double* R, int ldr, double* nrm);
+void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm);   // squared 2-norms
+void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m);
+// Y = a * d .* X + b * Y  (row scaling by d[i])
+void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,
+                    int m);
+void block_colscale(const Chunks& c, double* X, int ldx, int m, const double* colscale);  // X[:,j]*=cs[s*m+j]
+// deterministic counter-based start block; column 0 is the constant vector
+void block_init(const Chunks& c, double* X, int ldx, int m, const int* sub_gid, uint64_t seed);
+// Z_s (column-major, k_s columns of length n_s, at Z + zbase[s]):  Z_s[j][i] = d[i] * X[i][sel[s*m+j]]
+// (sel < 0 : the constant vector)
+void block_extract(const Chunks& c, const double* X, int ldx, int m, const double* d, const int* sel,
+                   const int* ksub, const int64_t* zbase, double* Z);
+
+// ---- coarse space ---------------------------------------------------------------------------
+// yE[zoff[s]+j] = sum_i Z_s[j][i] * xL[i] ; entries of yE not owned by a local subdomain are zeroed
+void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
+              int kmax, const double* xL, double* yE, int dimE_total);
+// wL[i] (+)= sum_j Z_s[j][i] * yE[zoff[s]+j]
+void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
+             const double* yE, double* wL, bool accumulate);
+
+// ---- misc -------------------------------------------------------------------------------------
+void  set_mfma(bool enable);   // false: run the plain-FMA twins of the MFMA kernels (validation)
+int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as the kernels assume
+void* event_create();
+void  event_record(void* ev);
+float event_elapsed_ms(void* a, void* b);   // syncs on b
+double hash_unit_host(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj);
+
+}  // namespace bk

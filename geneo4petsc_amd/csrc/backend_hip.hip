@@ -1,0 +1,1212 @@
+// HIP / CDNA4 (gfx950, MI355X) implementation of the device primitives in backend.h.
+// Wave = 64 lanes, 256-thread workgroups, FP64 data, 32-bit indices.
+//
+// Kernel inventory (roofline that bounds each, algorithmic bytes per unit -- see DESIGN.md):
+//   k_spmv_lds        CSR SpMV, LDS-staged row blocks, XCD-aware block remap       HBM  (12 B/nnz + 20 B/row)
+//   k_spmv_long       one workgroup per long row (> tile)                           HBM
+//   k_spmm            CSR x row-major multi-vector (fused D pre/post scaling)       HBM  (12 B/nnz + 16 m B/row)
+//   k_gram_mfma       tall-skinny S^T T, v_mfma_f64_16x16x4_f64, LDS slabs          MFMA/HBM ridge
+//   k_blockmul_mfma   tall-skinny S C update, v_mfma_f64_16x16x4_f64                MFMA/HBM ridge
+//   k_gram_fma / k_blockmul_fma   plain-FMA twins (GENEO_NO_MFMA=1; used to validate the MFMA maps)
+//   gather / segsum / BLAS-1 / chunked CG / z(t)_apply                              HBM
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e_) + " at " + \
+                               __FILE__ + ":" + std::to_string(__LINE__));                 \
+    }                                                                                      \
+  } while (0)
+
+namespace bk {
+
+static hipStream_t g_stream = nullptr;
+static bool g_no_mfma = false;
+static bool g_init = false;
+
+static void lazy_init() {
+  if (g_init) return;
+  g_init = true;
+  const char* e = getenv("GENEO_NO_MFMA");
+  g_no_mfma = (e && e[0] == '1');
+}
+
+const char* name() { return "hip-gfx950"; }
+void set_stream(void* s) { g_stream = (hipStream_t)s; }
+void* get_stream() { return (void*)g_stream; }
+void sync() { HIPCHK(hipStreamSynchronize(g_stream)); }
+
+void* alloc(size_t bytes) {
+  lazy_init();
+  void* p = nullptr;
+  if (bytes == 0) bytes = 8;
+  HIPCHK(hipMalloc(&p, bytes));
+  HIPCHK(hipMemsetAsync(p, 0, bytes, g_stream));
+  return p;
+}
+void dfree(void* p) {
+  if (p) (void)hipFree(p);
+}
+void h2d(void* d, const void* h, size_t bytes) {
+  if (!bytes) return;
+  HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));  // h may be pageable / reused by the caller
+}
+void d2h(void* h, const void* d, size_t bytes) {
+  if (!bytes) return;
+  HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+}
+void d2d(void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+}
+void zero(void* d, size_t bytes) {
+  if (!bytes) return;
+  HIPCHK(hipMemsetAsync(d, 0, bytes, g_stream));
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int grid1d(int64_t n, int per_block) {
+  int g = cdiv(n, per_block);
+  return g < 1 ? 1 : g;
+}
+
+// =============================================================================== CSR SpMV
+constexpr int SPMV_TILE = 1792;  // nnz staged in LDS per workgroup (14 KB): 256 rows x 7 nnz
+constexpr int SPMV_ROWS = 256;   // rows per row block (one row per thread in the reduce phase)
+
+Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
+  Csr a;
+  a.n = n;
+  a.nnz = h_rowptr[n];
+  a.rowptr = (int*)alloc(sizeof(int) * (size_t)(n + 1));
+  a.col = (int*)alloc(sizeof(int) * (size_t)a.nnz);
+  a.val = (double*)alloc(sizeof(double) * (size_t)a.nnz);
+  h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
+  h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
+  h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
+  // row blocks: as many consecutive rows as fit SPMV_TILE nnz and SPMV_ROWS rows; a row longer
+  // than the tile gets a block of its own (long-row path).
+  std::vector<int> blk;
+  blk.push_back(0);
+  int r = 0;
+  int maxrow = 0;
+  while (r < n) {
+    int r1 = r;
+    int nz = 0;
+    while (r1 < n && (r1 - r) < SPMV_ROWS) {
+      int len = h_rowptr[r1 + 1] - h_rowptr[r1];
+      maxrow = std::max(maxrow, len);
+      if (nz + len > SPMV_TILE) break;
+      nz += len;
+      ++r1;
+    }
+    if (r1 == r) ++r1;  // single long row
+    blk.push_back(r1);
+    r = r1;
+  }
+  a.max_row = maxrow;
+  a.nblk = (int)blk.size() - 1;
+  a.rowblk = (int*)alloc(sizeof(int) * blk.size());
+  h2d(a.rowblk, blk.data(), sizeof(int) * blk.size());
+  return a;
+}
+void csr_free(Csr& a) {
+  dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
+  a = Csr();
+}
+
+// XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs (b % 8 = XCD group).
+// Give each XCD a contiguous eighth of the row blocks so that its private 4 MiB L2 sees a
+// contiguous window of x instead of the whole vector.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+  const int per = (nblk + 7) >> 3;
+  const int t = (b & 7) * per + (b >> 3);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_spmv_lds(const int* __restrict__ rowblk, int nblk,
+                                                  const int* __restrict__ rowptr,
+                                                  const int* __restrict__ col,
+                                                  const double* __restrict__ val,
+                                                  const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double prod[SPMV_TILE];
+  const int t = xcd_remap(blockIdx.x, nblk);
+  if (t >= nblk) return;
+  const int r0 = rowblk[t], r1 = rowblk[t + 1];
+  const int nz0 = rowptr[r0], nz1 = rowptr[r1];
+  const int cnt = nz1 - nz0;
+  const int tid = threadIdx.x;
+  if (cnt > SPMV_TILE) {  // single long row: block-wide strided reduction
+    double s = 0.0;
+    for (int k = nz0 + tid; k < nz1; k += 256) s += val[k] * x[col[k]];
+    prod[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) prod[tid] += prod[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) y[r0] = prod[0];
+    return;
+  }
+  // phase 1: coalesced stream of (col,val), gather x, products into LDS
+  for (int k = tid; k < cnt; k += 256) prod[k] = val[nz0 + k] * x[col[nz0 + k]];
+  __syncthreads();
+  // phase 2: one row per thread, segmented sum out of LDS (fixed left-to-right order)
+  const int r = r0 + tid;
+  if (r < r1) {
+    const int a = rowptr[r] - nz0, b = rowptr[r + 1] - nz0;
+    double s = 0.0;
+    for (int k = a; k < b; ++k) s += prod[k];
+    y[r] = s;
+  }
+}
+
+void spmv(const Csr& a, const double* x, double* y) {
+  if (a.n == 0) return;
+  const int per = (a.nblk + 7) / 8;
+  hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
+                     a.col, a.val, x, y);
+}
+
+// =============================================================================== CSR SpMM
+// LPR lanes cooperate on one row, each lane owns columns j = lane, lane+LPR, ...
+template <int LPR>
+__global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ rowptr,
+                                              const int* __restrict__ col, const double* __restrict__ val,
+                                              const double* __restrict__ X, int ldx, double* __restrict__ Y,
+                                              int ldy, int m, const double* __restrict__ pre,
+                                              const double* __restrict__ post) {
+  constexpr int RPB = 256 / LPR;
+  const int lane = threadIdx.x % LPR;
+  const int rloc = threadIdx.x / LPR;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    for (int j = lane; j < m; j += LPR) {
+      double s = 0.0;
+      for (int k = a; k < b; ++k) {
+        const int c = col[k];
+        double v = val[k];
+        if (pre) v *= pre[c];
+        s += v * X[(int64_t)c * ldx + j];
+      }
+      if (post) s *= post[r];
+      Y[r * ldy + j] = s;
+    }
+  }
+}
+
+static void spmm_ld(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                    const double* post) {
+  if (a.n == 0 || m == 0) return;
+  if (m <= 16) {
+    int g = std::min(grid1d(a.n, 16), 8192);
+    hipLaunchKernelGGL(k_spmm<16>, dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, X, ldx, Y,
+                       ldy, m, pre, post);
+  } else if (m <= 32) {
+    int g = std::min(grid1d(a.n, 8), 8192);
+    hipLaunchKernelGGL(k_spmm<32>, dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, X, ldx, Y,
+                       ldy, m, pre, post);
+  } else {
+    int g = std::min(grid1d(a.n, 4), 8192);
+    hipLaunchKernelGGL(k_spmm<64>, dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, X, ldx, Y,
+                       ldy, m, pre, post);
+  }
+}
+void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                  const double* post) {
+  spmm_ld(a, X, ldx, Y, ldy, m, pre, post);
+}
+
+__global__ void k_csr_diag(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                           const double* __restrict__ val, double* __restrict__ d) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double v = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+    if (col[k] == r) v += val[k];
+  d[r] = v;
+}
+void csr_diag(const Csr& a, double* diag) {
+  if (a.n == 0) return;
+  hipLaunchKernelGGL(k_csr_diag, dim3(grid1d(a.n, 256)), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val,
+                     diag);
+}
+
+// =============================================================================== index kernels
+__global__ void k_gather(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ idx,
+                         const double* __restrict__ d, int n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = in[idx[i]];
+    if (d) v *= d[i];
+    out[i] = v;
+  }
+}
+void gather(double* out, const double* in, const int* idx, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather, dim3(std::min(grid1d(n, 256), 4096)), dim3(256), 0, g_stream, out, in, idx,
+                     (const double*)nullptr, n);
+}
+void gather_mul(double* out, const double* in, const int* idx, const double* d, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_gather, dim3(std::min(grid1d(n, 256), 4096)), dim3(256), 0, g_stream, out, in, idx, d, n);
+}
+__global__ void k_segsum(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ ptr,
+                         const int* __restrict__ idx, int nseg, int acc) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nseg; e += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = ptr[e]; k < ptr[e + 1]; ++k) s += in[idx[k]];
+    out[e] = acc ? out[e] + s : s;
+  }
+}
+void segsum(double* out, const double* in, const int* ptr, const int* idx, int nseg, bool accumulate) {
+  if (nseg <= 0) return;
+  hipLaunchKernelGGL(k_segsum, dim3(std::min(grid1d(nseg, 256), 4096)), dim3(256), 0, g_stream, out, in, ptr,
+                     idx, nseg, accumulate ? 1 : 0);
+}
+
+// =============================================================================== BLAS-1
+__global__ void k_set(double* x, double v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void k_axpby(double* __restrict__ y, double a, const double* __restrict__ x, double b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+__global__ void k_xmy(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * d[i];
+}
+__global__ void k_axpy_dev(double* __restrict__ y, const double* __restrict__ a, double sign,
+                           const double* __restrict__ x, int64_t n) {
+  const double s = sign * a[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += s * x[i];
+}
+static inline int gridv(int64_t n) { return std::min(grid1d(n, 1024), 2048); }
+void set(double* x, double v, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_set, dim3(gridv(n)), dim3(256), 0, g_stream, x, v, (int64_t)n);
+}
+void copy(double* y, const double* x, int n) { d2d(y, x, sizeof(double) * (size_t)n); }
+void axpy(double* y, double a, const double* x, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_axpby, dim3(gridv(n)), dim3(256), 0, g_stream, y, a, x, 1.0, (int64_t)n);
+}
+void axpby(double* y, double a, const double* x, double b, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_axpby, dim3(gridv(n)), dim3(256), 0, g_stream, y, a, x, b, (int64_t)n);
+}
+void xmy(double* y, const double* x, const double* d, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_xmy, dim3(gridv(n)), dim3(256), 0, g_stream, y, x, d, (int64_t)n);
+}
+void axpy_dev(double* y, const double* a_dev, double sign, const double* x, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_axpy_dev, dim3(gridv(n)), dim3(256), 0, g_stream, y, a_dev, sign, x, (int64_t)n);
+}
+
+// deterministic dot: fixed grid of DOT_BLOCKS partials, then one block sums them in order
+constexpr int DOT_BLOCKS = 1024;
+static double* g_dot_work = nullptr;
+int dot_work_doubles() { return DOT_BLOCKS; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* sm /*>=4*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];  // every thread gets the same, fixed-order value
+}
+__global__ __launch_bounds__(256) void k_dot1(const double* __restrict__ x, const double* __restrict__ y,
+                                              int64_t n, double* __restrict__ part) {
+  __shared__ double sm[4];
+  // contiguous slice per block -> fixed association independent of scheduling
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t a = (int64_t)blockIdx.x * per, b = (a + per < n) ? a + per : n;
+  double s = 0.0;
+  for (int64_t i = a + threadIdx.x; i < b; i += 256) s += x[i] * y[i];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_dot2(const double* __restrict__ part, int np, double* __restrict__ out) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) out[0] = s;
+}
+void dot(const double* x, const double* y, int n, double* out_dev) {
+  if (!g_dot_work) g_dot_work = (double*)alloc(sizeof(double) * DOT_BLOCKS);
+  int nb = std::min(DOT_BLOCKS, std::max(1, cdiv(n, 2048)));
+  hipLaunchKernelGGL(k_dot1, dim3(nb), dim3(256), 0, g_stream, x, y, (int64_t)n, g_dot_work);
+  hipLaunchKernelGGL(k_dot2, dim3(1), dim3(256), 0, g_stream, g_dot_work, nb, out_dev);
+}
+
+// =============================================================================== chunks
+Chunks chunks_upload(int nsub, const int* h_suboff) {
+  Chunks c;
+  c.nsub = nsub;
+  c.n = h_suboff[nsub];
+  std::vector<int> st, ln, sb, sp;
+  sp.push_back(0);
+  for (int s = 0; s < nsub; ++s) {
+    for (int a = h_suboff[s]; a < h_suboff[s + 1]; a += CHUNK) {
+      st.push_back(a);
+      ln.push_back(std::min(CHUNK, h_suboff[s + 1] - a));
+      sb.push_back(s);
+    }
+    sp.push_back((int)st.size());
+  }
+  c.nchunk = (int)st.size();
+  c.start = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
+  c.len = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
+  c.sub = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
+  c.subptr = (int*)alloc(sizeof(int) * sp.size());
+  c.partial = (double*)alloc(sizeof(double) * 4 * std::max<size_t>(1, st.size()));
+  c.suboff = (int*)alloc(sizeof(int) * (size_t)(nsub + 1));
+  h2d(c.suboff, h_suboff, sizeof(int) * (size_t)(nsub + 1));
+  h2d(c.start, st.data(), sizeof(int) * st.size());
+  h2d(c.len, ln.data(), sizeof(int) * ln.size());
+  h2d(c.sub, sb.data(), sizeof(int) * sb.size());
+  h2d(c.subptr, sp.data(), sizeof(int) * sp.size());
+  return c;
+}
+void gram_plan_drop(const Chunks& c);
+void chunks_free(Chunks& c) {
+  if (c.start) gram_plan_drop(c);
+  dfree(c.start); dfree(c.len); dfree(c.sub); dfree(c.subptr); dfree(c.partial); dfree(c.suboff);
+  c = Chunks();
+}
+
+// sum of the chunk partials of subdomain s (slot k), same fixed order in every workgroup
+__device__ __forceinline__ double sub_total(const double* __restrict__ part, int nchunk, int slot, int c0, int c1) {
+  double s = 0.0;
+  for (int c = c0; c < c1; ++c) s += part[(int64_t)slot * nchunk + c];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_seg_dot1(const int* __restrict__ start, const int* __restrict__ len,
+                                                  const double* __restrict__ x, const double* __restrict__ y,
+                                                  double* __restrict__ part, int nchunk, int slot) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
+  const int a = start[c], n = len[c];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[a + i] * y[a + i];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) part[(int64_t)slot * nchunk + c] = s;
+}
+__global__ void k_seg_dot2(const int* __restrict__ subptr, const double* __restrict__ part, int nchunk, int pslot,
+                           double* __restrict__ out, int stride, int slot, int nsub) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsub) return;
+  out[(int64_t)s * stride + slot] = sub_total(part, nchunk, pslot, subptr[s], subptr[s + 1]);
+}
+void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_seg_dot1, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, x, y, c.partial,
+                     c.nchunk, 3);
+  hipLaunchKernelGGL(k_seg_dot2, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk,
+                     3, out, stride, slot, c.nsub);
+}
+
+// --- batched CG (one independent CG per subdomain; scalars live in sc[s*8 + k]) -------------
+// sc slots: 0 rz(parity 0) 1 rz(parity 1) 2 pAp 3 rr 4 alpha 5 beta 6 active 7 rr0
+__global__ __launch_bounds__(256) void k_cg_start(const int* __restrict__ start, const int* __restrict__ len,
+                                                  double* __restrict__ x, double* __restrict__ r,
+                                                  double* __restrict__ z, double* __restrict__ p,
+                                                  const double* __restrict__ b, const double* __restrict__ dinv,
+                                                  double* __restrict__ part, int nchunk) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
+  const int a = start[c], n = len[c];
+  double rz = 0.0, rr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double rv = b[a + i];
+    const double zv = dinv[a + i] * rv;
+    x[a + i] = 0.0;
+    r[a + i] = rv;
+    z[a + i] = zv;
+    p[a + i] = zv;
+    rz += rv * zv;
+    rr += rv * rv;
+  }
+  rz = block_sum_256(rz, sm);
+  rr = block_sum_256(rr, sm);
+  if (threadIdx.x == 0) {
+    part[(int64_t)1 * nchunk + c] = rz;
+    part[(int64_t)2 * nchunk + c] = rr;
+  }
+}
+__global__ void k_cg_start2(const int* __restrict__ subptr, const double* __restrict__ part, int nchunk,
+                            double* __restrict__ sc, int nsub) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsub) return;
+  const double rz = sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
+  const double rr = sub_total(part, nchunk, 2, subptr[s], subptr[s + 1]);
+  double* q = sc + (int64_t)s * 8;
+  q[0] = rz; q[1] = rz; q[2] = 0.0; q[3] = rr; q[4] = 0.0; q[5] = 0.0;
+  q[6] = (rr > 0.0) ? 1.0 : 0.0;
+  q[7] = rr;
+}
+void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, double* p, const double* b,
+              const double* dinv) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_cg_start, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, x, r, z, p, b, dinv,
+                     c.partial, c.nchunk);
+  hipLaunchKernelGGL(k_cg_start2, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk,
+                     sc, c.nsub);
+}
+void seg_pap(const Chunks& c, const double* p, const double* q) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_seg_dot1, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, p, q, c.partial,
+                     c.nchunk, 0);
+}
+__global__ __launch_bounds__(256) void k_cg_update(const int* __restrict__ start, const int* __restrict__ len,
+                                                   const int* __restrict__ sub, const int* __restrict__ subptr,
+                                                   double* __restrict__ sc, int parity, double* __restrict__ x,
+                                                   double* __restrict__ r, double* __restrict__ z,
+                                                   const double* __restrict__ p, const double* __restrict__ q,
+                                                   const double* __restrict__ dinv, double* __restrict__ part,
+                                                   int nchunk) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
+  const int s = sub[c];
+  const int c0 = subptr[s], c1 = subptr[s + 1];
+  const double pap = sub_total(part, nchunk, 0, c0, c1);
+  const double rz = sc[(int64_t)s * 8 + parity];
+  const double active = sc[(int64_t)s * 8 + 6];
+  const double alpha = (active != 0.0 && pap != 0.0) ? rz / pap : 0.0;
+  const int a = start[c], n = len[c];
+  double nrz = 0.0, nrr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double xv = x[a + i] + alpha * p[a + i];
+    const double rv = r[a + i] - alpha * q[a + i];
+    const double zv = dinv[a + i] * rv;
+    x[a + i] = xv;
+    r[a + i] = rv;
+    z[a + i] = zv;
+    nrz += rv * zv;
+    nrr += rv * rv;
+  }
+  nrz = block_sum_256(nrz, sm);
+  nrr = block_sum_256(nrr, sm);
+  if (threadIdx.x == 0) {
+    part[(int64_t)1 * nchunk + c] = nrz;
+    part[(int64_t)2 * nchunk + c] = nrr;
+    if (c == c0) {
+      sc[(int64_t)s * 8 + 2] = pap;
+      sc[(int64_t)s * 8 + 4] = alpha;
+    }
+  }
+}
+void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, double* z, const double* p,
+                 const double* q, const double* dinv) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_cg_update, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.subptr, sc,
+                     parity, x, r, z, p, q, dinv, c.partial, c.nchunk);
+}
+__global__ __launch_bounds__(256) void k_cg_direction(const int* __restrict__ start, const int* __restrict__ len,
+                                                      const int* __restrict__ sub, const int* __restrict__ subptr,
+                                                      double* __restrict__ sc, int parity, double* __restrict__ p,
+                                                      const double* __restrict__ z, double tol2,
+                                                      const double* __restrict__ part, int nchunk) {
+  const int c = blockIdx.x;
+  const int s = sub[c];
+  const int c0 = subptr[s], c1 = subptr[s + 1];
+  const double nrz = sub_total(part, nchunk, 1, c0, c1);
+  const double nrr = sub_total(part, nchunk, 2, c0, c1);
+  const double rz = sc[(int64_t)s * 8 + parity];
+  const double was_active = sc[(int64_t)s * 8 + 6];
+  const double rr0 = sc[(int64_t)s * 8 + 7];
+  const double beta = (was_active != 0.0 && rz != 0.0) ? nrz / rz : 0.0;
+  const int a = start[c], n = len[c];
+  if (was_active != 0.0) {
+    for (int i = threadIdx.x; i < n; i += 256) p[a + i] = z[a + i] + beta * p[a + i];
+  }
+  if (threadIdx.x == 0 && c == c0) {
+    sc[(int64_t)s * 8 + (parity ^ 1)] = nrz;
+    sc[(int64_t)s * 8 + 3] = nrr;
+    sc[(int64_t)s * 8 + 5] = beta;
+    // NOTE: slot 6 is read by the other workgroups of this subdomain in THIS launch only through
+    // was_active loaded above; writing it here is ordered by the kernel boundary for later launches.
+  }
+  (void)tol2; (void)rr0;
+}
+// second tiny launch flips the active flag (separate launch => no intra-kernel read/write race)
+__global__ void k_cg_flag(double* __restrict__ sc, double tol2, int nsub) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsub) return;
+  double* q = sc + (int64_t)s * 8;
+  if (q[6] != 0.0 && q[3] <= tol2 * q[7]) q[6] = 0.0;
+}
+void cg_direction(const Chunks& c, double* sc, int parity, double* p, const double* z, double tol2) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_cg_direction, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.subptr, sc,
+                     parity, p, z, tol2, c.partial, c.nchunk);
+  hipLaunchKernelGGL(k_cg_flag, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, sc, tol2, c.nsub);
+}
+
+// =============================================================================== tall-skinny blocks
+// Gram row ranges: GRAM_CH consecutive chunks of one subdomain per workgroup.
+constexpr int GRAM_CH = 4;
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+// G_partial[blk] (p x q) = S[rows]^T T[rows].  MFMA v_mfma_f64_16x16x4_f64:
+//   A operand lane l: A[i = l&15][k = l>>4]   -> S[row0 + 4*step + (l>>4)][16*I + (l&15)]
+//   B operand lane l: B[k = l>>4][j = l&15]   -> T[row0 + 4*step + (l>>4)][16*J + (l&15)]
+//   C/D lane l, reg v: row i = (l>>4) + 4*v, col j = l&15         (cdna_hip_programming.md s3)
+// 4 waves; wave w owns output tiles t = w, w+4, ... (t = I*Q16 + J), at most TPW tiles.
+template <int TPW>
+__global__ __launch_bounds__(256) void k_gram_mfma(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                   const int* __restrict__ gfirst, const int* __restrict__ gcount,
+                                                   const double* __restrict__ S, int lds_, int p,
+                                                   const double* __restrict__ T, int ldt_, int q,
+                                                   double* __restrict__ Gpart, int tile0) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int ldS = (p % 32 == 0) ? p + 16 : p;  // rows r, r+1 land 32 banks apart
+  const int ldT = (q % 32 == 0) ? q + 16 : q;
+  double* sS = smem;             // 16 x ldS
+  double* sT = smem + 16 * ldS;  // 16 x ldT
+  const int g = blockIdx.x;
+  const int c0 = gfirst[g], nc = gcount[g];
+  const int row0 = cstart[c0];
+  int nrows = 0;
+  for (int c = 0; c < nc; ++c) nrows += clen[c0 + c];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int P16 = p >> 4, Q16 = q >> 4, NT = P16 * Q16;
+  d4 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < nrows; r += 16) {
+    const int nr = (nrows - r < 16) ? nrows - r : 16;
+    __syncthreads();
+    for (int e = tid; e < 16 * p; e += 256) {
+      const int rr = e / p, cc = e - rr * p;
+      sS[rr * ldS + cc] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
+    }
+    for (int e = tid; e < 16 * q; e += 256) {
+      const int rr = e / q, cc = e - rr * q;
+      sT[rr * ldT + cc] = (rr < nr) ? T[(int64_t)(row0 + r + rr) * ldt_ + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int kr = 4 * step + (l >> 4);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = tile0 + w + 4 * i;
+        if (t < NT) {
+          const int I = t / Q16, J = t - I * Q16;
+          const double a = sS[kr * ldS + 16 * I + (l & 15)];
+          const double b = sT[kr * ldT + 16 * J + (l & 15)];
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  double* G = Gpart + (int64_t)g * p * q;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = tile0 + w + 4 * i;
+    if (t < NT) {
+      const int I = t / Q16, J = t - I * Q16;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * I + (l >> 4) + 4 * v, colj = 16 * J + (l & 15);
+        G[(int64_t)row * q + colj] = acc[i][v];
+      }
+    }
+  }
+}
+
+// plain-FMA twin (any p, q): each thread owns output entries e = tid, tid+256, ...
+__global__ __launch_bounds__(256) void k_gram_fma(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                  const int* __restrict__ gfirst, const int* __restrict__ gcount,
+                                                  const double* __restrict__ S, int lds_, int p,
+                                                  const double* __restrict__ T, int ldt_, int q,
+                                                  double* __restrict__ Gpart) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sS = smem;           // 16 x p
+  double* sT = smem + 16 * p;  // 16 x q
+  const int g = blockIdx.x;
+  const int c0 = gfirst[g], nc = gcount[g];
+  const int row0 = cstart[c0];
+  int nrows = 0;
+  for (int c = 0; c < nc; ++c) nrows += clen[c0 + c];
+  const int tid = threadIdx.x;
+  const int npq = p * q;
+  constexpr int MAXE = 40;  // 256*40 = 10240 >= 96*96
+  double acc[MAXE];
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) acc[i] = 0.0;
+  for (int r = 0; r < nrows; r += 16) {
+    const int nr = (nrows - r < 16) ? nrows - r : 16;
+    __syncthreads();
+    for (int e = tid; e < 16 * p; e += 256) {
+      const int rr = e / p, cc = e - rr * p;
+      sS[e] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
+    }
+    for (int e = tid; e < 16 * q; e += 256) {
+      const int rr = e / q, cc = e - rr * q;
+      sT[e] = (rr < nr) ? T[(int64_t)(row0 + r + rr) * ldt_ + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int e = tid + 256 * i;
+      if (e < npq) {
+        const int a = e / q, b = e - a * q;
+        double s = acc[i];
+        for (int rr = 0; rr < 16; ++rr) s += sS[rr * p + a] * sT[rr * q + b];
+        acc[i] = s;
+      }
+    }
+  }
+  double* G = Gpart + (int64_t)g * npq;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = tid + 256 * i;
+    if (e < npq) G[e] = acc[i];
+  }
+}
+
+// sum the partial Grams of each subdomain in fixed order
+__global__ void k_gram_reduce(const int* __restrict__ gsubptr, const double* __restrict__ Gpart, int pq,
+                              double* __restrict__ G) {
+  const int s = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= pq) return;
+  double acc = 0.0;
+  for (int g = gsubptr[s]; g < gsubptr[s + 1]; ++g) acc += Gpart[(int64_t)g * pq + e];
+  G[(int64_t)s * pq + e] = acc;
+}
+
+// host-side cache of the gram grouping for a Chunks object (keyed by its device pointer)
+struct GramPlan {
+  const int* key = nullptr;
+  int ngroup = 0, nsub = 0;
+  int *gfirst = nullptr, *gcount = nullptr, *gsubptr = nullptr;
+  double* part = nullptr;
+  size_t part_doubles = 0;
+};
+static std::vector<GramPlan> g_plans;
+static GramPlan& gram_plan(const Chunks& c) {
+  for (auto& pl : g_plans)
+    if (pl.key == c.start) return pl;
+  GramPlan pl;
+  pl.key = c.start;
+  pl.nsub = c.nsub;
+  std::vector<int> sp(c.nsub + 1);
+  d2h(sp.data(), c.subptr, sizeof(int) * (c.nsub + 1));
+  std::vector<int> gf, gc, gs;
+  gs.push_back(0);
+  for (int s = 0; s < c.nsub; ++s) {
+    for (int a = sp[s]; a < sp[s + 1]; a += GRAM_CH) {
+      gf.push_back(a);
+      gc.push_back(std::min(GRAM_CH, sp[s + 1] - a));
+    }
+    gs.push_back((int)gf.size());
+  }
+  pl.ngroup = (int)gf.size();
+  pl.gfirst = (int*)alloc(sizeof(int) * std::max<size_t>(1, gf.size()));
+  pl.gcount = (int*)alloc(sizeof(int) * std::max<size_t>(1, gc.size()));
+  pl.gsubptr = (int*)alloc(sizeof(int) * gs.size());
+  h2d(pl.gfirst, gf.data(), sizeof(int) * gf.size());
+  h2d(pl.gcount, gc.data(), sizeof(int) * gc.size());
+  h2d(pl.gsubptr, gs.data(), sizeof(int) * gs.size());
+  g_plans.push_back(pl);
+  return g_plans.back();
+}
+void gram_plan_drop(const Chunks& c) {
+  for (size_t i = 0; i < g_plans.size(); ++i)
+    if (g_plans[i].key == c.start) {
+      dfree(g_plans[i].gfirst); dfree(g_plans[i].gcount); dfree(g_plans[i].gsubptr); dfree(g_plans[i].part);
+      g_plans.erase(g_plans.begin() + i);
+      return;
+    }
+}
+
+void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, int ldt_, int q, double* G) {
+  if (c.nchunk == 0 || p == 0 || q == 0) return;
+  GramPlan& pl = gram_plan(c);
+  const size_t need = (size_t)pl.ngroup * p * q;
+  if (pl.part_doubles < need) {
+    dfree(pl.part);
+    pl.part = (double*)alloc(sizeof(double) * need);
+    pl.part_doubles = need;
+  }
+  const bool mfma_ok = !g_no_mfma && (p % 16 == 0) && (q % 16 == 0) && p <= 192 && q <= 192;
+  if (mfma_ok) {
+    const int ldS = (p % 32 == 0) ? p + 16 : p, ldT = (q % 32 == 0) ? q + 16 : q;
+    const size_t sm = sizeof(double) * 16 * (size_t)(ldS + ldT);
+    const int NT = (p / 16) * (q / 16);
+    constexpr int TPW = 9;  // 36 tiles per launch (p = q = 96)
+    for (int tile0 = 0; tile0 < NT; tile0 += 4 * TPW) {
+      hipLaunchKernelGGL(k_gram_mfma<TPW>, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst,
+                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, tile0);
+    }
+  } else {
+    if ((size_t)p * q > 256 * 40) throw std::runtime_error("gram: p*q too large for the FMA kernel");
+    const size_t sm = sizeof(double) * 16 * (size_t)(p + q);
+    hipLaunchKernelGGL(k_gram_fma, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, pl.gcount,
+                       S, lds_, p, T, ldt_, q, pl.part);
+  }
+  hipLaunchKernelGGL(k_gram_reduce, dim3(grid1d(p * q, 256), c.nsub), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
+                     p * q, G);
+}
+
+// Y[rows] (+)= S[rows] C_s : one workgroup per chunk, 64-row slabs of S through LDS, the wave's
+// B fragments (its 16 output columns of C_s) held in registers for the whole chunk.
+//   A operand lane l: A[i = l&15][k = l>>4] -> S[r + (l&15)][4*kk + (l>>4)]   (LDS, ld = 2 mod 32:
+//                     the 32 lanes of a ds_read_b64 group hit 32 distinct 8-byte banks)
+//   B operand lane l: B[k = l>>4][j = l&15] -> C[4*kk + (l>>4)][16*J + (l&15)] (registers)
+//   D lane l, reg v : Y[r + (l>>4) + 4v][16*J + (l&15)]
+// Wave w -> column tile J = Jbase + (w % nJ), row tiles rt = w / nJ, + 4/nJ, ...  (nJ = min(Q16,4))
+template <int P4>
+__global__ __launch_bounds__(256) void k_blockmul_mfma(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                       const int* __restrict__ csub, const double* __restrict__ S,
+                                                       int lds_, const double* __restrict__ C, int q,
+                                                       double* __restrict__ Y, int ldy, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int p = 4 * P4;
+  constexpr int ldS = p + ((34 - (p % 32)) % 32);  // = 2 (mod 32)
+  double* sS = smem;                               // 64 x ldS
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const double* Cs = C + (int64_t)s * p * q;
+  const int Q16 = q >> 4;
+  const int nJ = Q16 < 4 ? Q16 : 4;  // Q16 in {1,2,4,8,...}
+  const int rtw = 4 / nJ;            // waves sharing one column tile
+  const int jsel = w % nJ, rsel = w / nJ;
+  for (int Jbase = 0; Jbase < Q16; Jbase += nJ) {
+    const int J = Jbase + jsel;
+    double bfrag[P4];
+#pragma unroll
+    for (int kk = 0; kk < P4; ++kk) bfrag[kk] = Cs[(int64_t)(4 * kk + (l >> 4)) * q + 16 * J + (l & 15)];
+    for (int r = 0; r < nrows; r += 64) {
+      const int nr = (nrows - r < 64) ? nrows - r : 64;
+      __syncthreads();
+      for (int e = tid; e < 64 * p; e += 256) {
+        const int rr = e / p, cc = e - rr * p;
+        sS[rr * ldS + cc] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
+      }
+      __syncthreads();
+      for (int rt = rsel; rt < 4; rt += rtw) {
+        if (16 * rt >= nr) break;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        if (accumulate) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * rt + (l >> 4) + 4 * v;
+            if (rr < nr) acc[v] = Y[(int64_t)(row0 + r + rr) * ldy + 16 * J + (l & 15)];
+          }
+        }
+        const double* arow = sS + (16 * rt + (l & 15)) * ldS + (l >> 4);
+#pragma unroll
+        for (int kk = 0; kk < P4; ++kk)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * kk], bfrag[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int rr = 16 * rt + (l >> 4) + 4 * v;
+          if (rr < nr) Y[(int64_t)(row0 + r + rr) * ldy + 16 * J + (l & 15)] = acc[v];
+        }
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_blockmul_fma(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                      const int* __restrict__ csub, const double* __restrict__ S,
+                                                      int lds_, int p, const double* __restrict__ C, int q,
+                                                      double* __restrict__ Y, int ldy, int accumulate) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const double* Cs = C + (int64_t)s * p * q;
+  for (int e = threadIdx.x; e < nrows * q; e += 256) {
+    const int rr = e / q, j = e - rr * q;
+    const double* srow = S + (int64_t)(row0 + rr) * lds_;
+    double acc = accumulate ? Y[(int64_t)(row0 + rr) * ldy + j] : 0.0;
+    for (int k = 0; k < p; ++k) acc += srow[k] * Cs[k * q + j];
+    Y[(int64_t)(row0 + rr) * ldy + j] = acc;
+  }
+}
+template <int P4>
+static void launch_blockmul(const Chunks& c, const double* S, int lds_, const double* C, int q, double* Y, int ldy,
+                            bool accumulate) {
+  constexpr int p = 4 * P4;
+  constexpr int ldS = p + ((34 - (p % 32)) % 32);
+  const size_t sm = sizeof(double) * (size_t)64 * ldS;
+  static bool attr_done = false;
+  if (sm > 64 * 1024 && !attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_blockmul_mfma<P4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sm));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_blockmul_mfma<P4>, dim3(c.nchunk), dim3(256), sm, g_stream, c.start, c.len, c.sub, S, lds_,
+                     C, q, Y, ldy, accumulate ? 1 : 0);
+}
+void block_mul(const Chunks& c, const double* S, int lds_, int p, const double* C, int q, double* Y, int ldy,
+               bool accumulate) {
+  if (c.nchunk == 0 || p == 0 || q == 0) return;
+  const int Q16 = q / 16;
+  const bool qok = (q % 16 == 0) && (Q16 == 1 || Q16 == 2 || (Q16 % 4 == 0));
+  if (!g_no_mfma && qok && p % 4 == 0) {
+    switch (p / 4) {
+      case 4:  launch_blockmul<4>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 8:  launch_blockmul<8>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 12: launch_blockmul<12>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 16: launch_blockmul<16>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 24: launch_blockmul<24>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 32: launch_blockmul<32>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      case 48: launch_blockmul<48>(c, S, lds_, C, q, Y, ldy, accumulate); return;
+      default: break;
+    }
+  }
+  hipLaunchKernelGGL(k_blockmul_fma, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, lds_, p, C,
+                     q, Y, ldy, accumulate ? 1 : 0);
+}
+
+// per-chunk column sums -> per-subdomain column sums (fixed order)
+__global__ void k_colsum_reduce(const int* __restrict__ subptr, const double* __restrict__ part, int m,
+                                double* __restrict__ out) {
+  const int s = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j >= m) return;
+  double t = 0.0;
+  for (int c = subptr[s]; c < subptr[s + 1]; ++c) t += part[(int64_t)c * m + j];
+  out[(int64_t)s * m + j] = t;
+}
+static double* g_colpart = nullptr;
+static size_t g_colpart_n = 0;
+static double* colpart(size_t n) {
+  if (g_colpart_n < n) {
+    dfree(g_colpart);
+    g_colpart = (double*)alloc(sizeof(double) * n);
+    g_colpart_n = n;
+  }
+  return g_colpart;
+}
+
+// R = AX - BX diag(lam_s); column squared norms per subdomain
+__global__ __launch_bounds__(256) void k_block_residual(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                        const int* __restrict__ csub, const double* __restrict__ AX,
+                                                        int lda, const double* __restrict__ BX, int ldb,
+                                                        const double* __restrict__ lam, int m,
+                                                        double* __restrict__ R, int ldr, double* __restrict__ part) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int tid = threadIdx.x;
+  const int rstep = 256 / m;  // m <= 256
+  const int j = tid % m, rr0 = tid / m;
+  double acc = 0.0;
+  if (tid < rstep * m) {
+    const double lj = lam[(int64_t)s * m + j];
+    for (int rr = rr0; rr < nrows; rr += rstep) {
+      const int64_t row = row0 + rr;
+      const double v = AX[row * lda + j] - lj * BX[row * ldb + j];
+      R[row * ldr + j] = v;
+      acc += v * v;
+    }
+  }
+  sm[tid] = (tid < rstep * m) ? acc : 0.0;
+  __syncthreads();
+  if (tid < m) {
+    double t = 0.0;
+    for (int k = 0; k < rstep; ++k) t += sm[k * m + tid];
+    part[(int64_t)c * m + tid] = t;
+  }
+}
+void block_residual(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam, int m,
+                    double* R, int ldr, double* nrm) {
+  if (c.nchunk == 0) return;
+  if (m > 256) throw std::runtime_error("block_residual: m > 256");
+  double* part = colpart((size_t)c.nchunk * m);
+  hipLaunchKernelGGL(k_block_residual, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, AX, lda, BX,
+                     ldb, lam, m, R, ldr, part);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((m + 63) / 64) * 64), 0, g_stream, c.subptr, part, m, nrm);
+}
+__global__ __launch_bounds__(256) void k_block_colnorm(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                       const double* __restrict__ X, int ldx, int m,
+                                                       double* __restrict__ part) {
+  __shared__ double sm[256];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c];
+  const int tid = threadIdx.x;
+  const int rstep = 256 / m;
+  const int j = tid % m, rr0 = tid / m;
+  double acc = 0.0;
+  if (tid < rstep * m)
+    for (int rr = rr0; rr < nrows; rr += rstep) {
+      const double v = X[(int64_t)(row0 + rr) * ldx + j];
+      acc += v * v;
+    }
+  sm[tid] = (tid < rstep * m) ? acc : 0.0;
+  __syncthreads();
+  if (tid < m) {
+    double t = 0.0;
+    for (int k = 0; k < rstep; ++k) t += sm[k * m + tid];
+    part[(int64_t)c * m + tid] = t;
+  }
+}
+void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm) {
+  if (c.nchunk == 0) return;
+  if (m > 256) throw std::runtime_error("block_colnorm: m > 256");
+  double* part = colpart((size_t)c.nchunk * m);
+  hipLaunchKernelGGL(k_block_colnorm, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, X, ldx, m, part);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((m + 63) / 64) * 64), 0, g_stream, c.subptr, part, m, nrm);
+}
+
+// strided elementwise: Y[i][j] = a*X[i][j] + b*Y[i][j]   (b == 0 => pure assignment, Y not read)
+__global__ void k_block_axpby(double* __restrict__ Y, int ldy, double a, const double* __restrict__ X, int ldx,
+                              double b, int64_t n, int m) {
+  const int64_t tot = n * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / m;
+    const int j = (int)(e - i * m);
+    const double xv = a * X[i * ldx + j];
+    Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
+  }
+}
+void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m) {
+  if (n <= 0 || m <= 0) return;
+  hipLaunchKernelGGL(k_block_axpby, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, Y, ldy, a, X, ldx, b,
+                     (int64_t)n, m);
+}
+// Y[i][j] = a * d[i] * X[i][j] + b*Y[i][j]
+__global__ void k_block_rowscale(double* __restrict__ Y, int ldy, const double* __restrict__ X, int ldx,
+                                 const double* __restrict__ d, double a, double b, int64_t n, int m) {
+  const int64_t tot = n * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / m;
+    const int j = (int)(e - i * m);
+    const double xv = a * d[i] * X[i * ldx + j];
+    Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
+  }
+}
+void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n, int m) {
+  if (n <= 0 || m <= 0) return;
+  hipLaunchKernelGGL(k_block_rowscale, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, Y, ldy, X, ldx, d, a, b,
+                     (int64_t)n, m);
+}
+__global__ __launch_bounds__(256) void k_block_colscale(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                        const int* __restrict__ csub, double* __restrict__ X, int ldx,
+                                                        int m, const double* __restrict__ cs) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  for (int e = threadIdx.x; e < nrows * m; e += 256) {
+    const int rr = e / m, j = e - rr * m;
+    X[(int64_t)(row0 + rr) * ldx + j] *= cs[(int64_t)s * m + j];
+  }
+}
+void block_colscale(const Chunks& c, double* X, int ldx, int m, const double* colscale) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_block_colscale, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, X, ldx, m,
+                     colscale);
+}
+
+// counter-based start block (splitmix64 of (seed, global subdomain id, local row, column))
+__host__ __device__ inline double hash_unit(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xBF58476D1CE4E5B9ull * (row + 1) +
+               0x94D049BB133111EBull * (colj + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;  // [-0.5, 0.5)
+}
+double hash_unit_host(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj) {
+  return hash_unit(seed, gid, row, colj);
+}
+__global__ __launch_bounds__(256) void k_block_init(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                    const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                    double* __restrict__ X, int ldx, int m,
+                                                    const int* __restrict__ sub_gid, uint64_t seed) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int sub_row0 = suboff[s];
+  for (int e = threadIdx.x; e < nrows * m; e += 256) {
+    const int rr = e / m, j = e - rr * m;
+    const int64_t lrow = (int64_t)(row0 + rr) - sub_row0;
+    X[(int64_t)(row0 + rr) * ldx + j] =
+        (j == 0) ? 1.0 : hash_unit(seed, (uint64_t)sub_gid[s], (uint64_t)lrow, (uint64_t)j);
+  }
+}
+void block_init(const Chunks& c, double* X, int ldx, int m, const int* sub_gid, uint64_t seed) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_block_init, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, X, ldx,
+                     m, sub_gid, seed);
+}
+
+__global__ __launch_bounds__(256) void k_block_extract(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                       const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                       const double* __restrict__ X, int ldx, int m,
+                                                       const double* __restrict__ d, const int* __restrict__ sel,
+                                                       const int* __restrict__ ksub, const int64_t* __restrict__ zbase,
+                                                       double* __restrict__ Z) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int k = ksub[s];
+  const int srow0 = suboff[s];
+  const int ns = suboff[s + 1] - srow0;
+  double* Zs = Z + zbase[s];
+  for (int j = 0; j < k; ++j) {
+    const int src = sel[(int64_t)s * m + j];
+    for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+      const int64_t row = row0 + rr;
+      const double v = (src < 0) ? 1.0 : X[row * ldx + src];  // src < 0: constant (Nicolaides) vector
+      Zs[(int64_t)j * ns + (row - srow0)] = d[row] * v;
+    }
+  }
+}
+void block_extract(const Chunks& c, const double* X, int ldx, int m, const double* d, const int* sel,
+                   const int* ksub, const int64_t* zbase, double* Z) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_block_extract, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, X,
+                     ldx, m, d, sel, ksub, zbase, Z);
+}
+
+// =============================================================================== coarse space
+// Z_s column-major (k_s columns of length n_s).  One workgroup per chunk: x chunk in registers,
+// loop over the k_s columns (coalesced), chunk partial per column, then ordered reduce.
+constexpr int ZMAXK = 256;
+__global__ __launch_bounds__(256) void k_zt_apply(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                  const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                  const double* __restrict__ Z, const int64_t* __restrict__ zbase,
+                                                  const int* __restrict__ ksub, const double* __restrict__ xL,
+                                                  double* __restrict__ part, int kmax) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int k = ksub[s];
+  const int srow0 = suboff[s];
+  const int ns = suboff[s + 1] - srow0;
+  const double* Zs = Z + zbase[s];
+  double xv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int rr = threadIdx.x + 256 * u;
+    xv[u] = (rr < nrows) ? xL[row0 + rr] : 0.0;
+  }
+  for (int j = 0; j < k; ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = threadIdx.x + 256 * u;
+      if (rr < nrows) acc += Zs[(int64_t)j * ns + (row0 - srow0) + rr] * xv[u];
+    }
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[(int64_t)c * kmax + j] = acc;
+  }
+}
+__global__ void k_zt_reduce(const int* __restrict__ subptr, const int* __restrict__ ksub, const int* __restrict__ zoff,
+                            const double* __restrict__ part, int kmax, double* __restrict__ yE) {
+  const int s = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j >= ksub[s]) return;
+  double t = 0.0;
+  for (int c = subptr[s]; c < subptr[s + 1]; ++c) t += part[(int64_t)c * kmax + j];
+  yE[zoff[s] + j] = t;
+}
+void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff, int kmax,
+              const double* xL, double* yE, int dimE_total) {
+  if (kmax > ZMAXK) throw std::runtime_error("zt_apply: more than 256 coarse vectors in one subdomain");
+  zero(yE, sizeof(double) * (size_t)dimE_total);
+  if (c.nchunk == 0 || kmax == 0) return;
+  double* part = colpart((size_t)c.nchunk * kmax);
+  hipLaunchKernelGGL(k_zt_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, Z, zbase,
+                     ksub, xL, part, kmax);
+  hipLaunchKernelGGL(k_zt_reduce, dim3(c.nsub), dim3(((kmax + 63) / 64) * 64), 0, g_stream, c.subptr, ksub, zoff,
+                     part, kmax, yE);
+}
+__global__ __launch_bounds__(256) void k_z_apply(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                 const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                 const double* __restrict__ Z, const int64_t* __restrict__ zbase,
+                                                 const int* __restrict__ ksub, const int* __restrict__ zoff,
+                                                 const double* __restrict__ yE, double* __restrict__ wL, int acc) {
+  __shared__ double sy[ZMAXK];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int k = ksub[s];
+  const int srow0 = suboff[s];
+  const int ns = suboff[s + 1] - srow0;
+  const double* Zs = Z + zbase[s];
+  for (int j = threadIdx.x; j < k; j += 256) sy[j] = yE[zoff[s] + j];
+  __syncthreads();
+  for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+    double a = 0.0;
+    for (int j = 0; j < k; ++j) a += Zs[(int64_t)j * ns + (row0 - srow0) + rr] * sy[j];
+    wL[row0 + rr] = acc ? wL[row0 + rr] + a : a;
+  }
+}
+void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
+             const double* yE, double* wL, bool accumulate) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_z_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, Z, zbase,
+                     ksub, zoff, yE, wL, accumulate ? 1 : 0);
+}
+
+// =============================================================================== self test / events
+// A = I(16x16 in the first 4 k-steps pattern) check of the f64 MFMA operand/result maps.
+__global__ void k_mfma_selftest(double* out) {
+  const int l = threadIdx.x;
+  // C = A(16x4) * B(4x16) with A[i][k] = (i == k), B[k][j] = 100*k + j  ->  C[i][j] = B[i][j] for i<4 else 0
+  const int i = l & 15, k = l >> 4;
+  const double a = (i == k) ? 1.0 : 0.0;
+  const double b = 100.0 * k + (l & 15);
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  for (int v = 0; v < 4; ++v) {
+    const int row = (l >> 4) + 4 * v, colj = l & 15;
+    out[row * 16 + colj] = acc[v];
+  }
+}
+void set_mfma(bool enable) { lazy_init(); g_no_mfma = !enable; }
+int selftest_mfma_f64() {
+  double* d = (double*)alloc(sizeof(double) * 256);
+  hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, g_stream, d);
+  double h[256];
+  d2h(h, d, sizeof(h));
+  dfree(d);
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      const double want = (i < 4) ? 100.0 * i + j : 0.0;
+      if (h[i * 16 + j] != want) return 1 + i * 16 + j;
+    }
+  return 0;
+}
+
+void* event_create() {
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  return (void*)e;
+}
+void event_record(void* ev) { HIPCHK(hipEventRecord((hipEvent_t)ev, g_stream)); }
+float event_elapsed_ms(void* a, void* b) {
+  HIPCHK(hipEventSynchronize((hipEvent_t)b));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b));
+  return ms;
+}
+
+}  // namespace bk

@@ -1,0 +1,454 @@
+// extern "C" entry points of libgeneopc (declared in include/geneo_c.h).
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "../../include/geneo_c.h"
+#include "core.h"
+
+struct _p_GeneoPC {
+  geneo::PC* ctx = nullptr;   // pc->data in PETSc (src/geneo.cpp:2645)
+  std::string name, err;
+  // PCSetOperators_GenEO copy (the MATIS A of the one-subdomain-per-rank model)
+  bool has_ops = false;
+  int nbDOF = 0, nbDOFLoc = 0;
+  std::vector<int> map, rowptr, col;
+  std::vector<double> val;
+  const double* b_dev = nullptr;
+};
+
+struct _p_GeneoSpmv {
+  bk::Csr a;
+};
+
+static std::string g_global_err;
+
+#define GUARD_BEGIN try {
+#define GUARD_END(pc)                                \
+  }                                                  \
+  catch (std::exception & e) {                       \
+    if (pc) (pc)->err = e.what();                    \
+    else g_global_err = e.what();                    \
+    return 1;                                        \
+  }
+
+static int pcfail(PC pc, const std::string& m) {
+  if (pc) pc->err = m;
+  return 1;
+}
+static int propagate(PC pc, int rc) {
+  if (rc && pc && pc->ctx) pc->err = pc->ctx->last_error;
+  return rc;
+}
+
+extern "C" {
+
+PetscErrorCode PCCreate_GenEO(PC* pc) {
+  if (!pc) return 1;
+  *pc = new _p_GeneoPC();
+  return createGenEOPC(*pc);
+}
+
+PetscErrorCode createGenEOPC(PC pc) {
+  if (!pc) return 1;  // "GenEO preconditioner is invalid"
+  delete pc->ctx;
+  pc->ctx = new geneo::PC();
+  pc->name = pc->ctx->opt.name();
+  return 0;
+}
+
+PetscErrorCode PCDestroy_GenEO(PC* pc) {
+  if (!pc || !*pc) return 0;
+  GUARD_BEGIN
+  delete (*pc)->ctx;
+  delete *pc;
+  *pc = nullptr;
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
+static const char* kFlagOptions[] = {"-geneo_cst", "-geneo_no_syl", "-geneo_offload"};
+static bool is_flag(const std::string& k) {
+  for (const char* f : kFlagOptions)
+    if (k == f) return true;
+  return false;
+}
+
+PetscErrorCode PCGenEOSetOption(PC pc, const char* key, const char* value) {
+  if (!pc || !pc->ctx) return 1;
+  const std::string k = key ? key : "", v = value ? value : "";
+  std::string e = geneo::parse_option(pc->ctx->opt, k, v);
+  if (!e.empty()) return pcfail(pc, e);
+  e = geneo::validate_options(pc->ctx->opt);
+  if (!e.empty()) return pcfail(pc, e);
+  pc->name = pc->ctx->opt.name();
+  return 0;
+}
+
+PetscErrorCode PCSetFromOptions_GenEO(PC pc, int argc, const char* const* argv) {
+  if (!pc || !pc->ctx) return 1;
+  for (int i = 0; i < argc; ++i) {
+    const std::string k = argv[i] ? argv[i] : "";
+    if (k.empty() || k[0] != '-') continue;
+    if (is_flag(k)) {
+      geneo::parse_option(pc->ctx->opt, k, "");
+      continue;
+    }
+    const bool known = k.rfind("-geneo_", 0) == 0 || k.rfind("-els2_", 0) == 0 || k.rfind("-dls1_", 0) == 0 ||
+                       k.rfind("-ksp_", 0) == 0;
+    if (!known) continue;
+    if (i + 1 >= argc) return pcfail(pc, "invalid option " + k);
+    const std::string v = argv[i + 1];
+    std::string e = geneo::parse_option(pc->ctx->opt, k, v);
+    if (!e.empty()) {
+      if (e.rfind("unknown option", 0) == 0) continue;  // forwarded prefix this build does not use
+      return pcfail(pc, e);
+    }
+    ++i;
+  }
+  std::string e = geneo::validate_options(pc->ctx->opt);
+  if (!e.empty()) return pcfail(pc, e);
+  pc->name = pc->ctx->opt.name();
+  return 0;
+}
+
+const char* PCGenEOGetName(PC pc) { return pc ? pc->name.c_str() : ""; }
+const char* PCGenEOGetError(PC pc) { return pc ? pc->err.c_str() : g_global_err.c_str(); }
+
+const char* usageGenEO_c(void) {
+  return "\nusage: GenEO (Domain Decomposition Method) on MI355X\n\n"
+         "  -geneo_lvl L1,L2 preconditioner with 2 levels L1 and L2\n"
+         "                   L1 = ASM | RAS | SRAS | ORAS | SORAS\n"
+         "                   L2 = 0 | 1 | H1 | E1 | 2 | H2 | E2\n"
+         "  -geneo_optim A   robin = dirichlet + optim * neumann (ORAS, SORAS; defaults to 0.)\n"
+         "  -geneo_tau T     tau threshold (defaults to 0.1)\n"
+         "  -geneo_gamma G   gamma threshold (defaults to 10.)\n"
+         "  -geneo_cst       do not allow local variations of tau and gamma (GenEO-2)\n"
+         "  -geneo_cut C     maximum number of local eigen vectors used to build Z\n"
+         "  -geneo_no_syl    accepted for compatibility (no inertia estimate on the GPU path)\n"
+         "  -geneo_offload   accepted for compatibility (E is replicated on every GPU)\n"
+         "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_cheb_degree / -els2_cheb_ratio\n"
+         "  -dls1_ksp_rtol / -dls1_ksp_max_it   local solves (batched Jacobi-PCG)\n"
+         "  -ksp_type cg|gmres -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart\n\n";
+}
+
+PetscErrorCode PCSetOperators_GenEO(PC pc, const GeneoMatIS* A) {
+  if (!pc || !A) return 1;
+  if (!A->map || !A->local.rowptr || A->local.n != A->nbDOFLoc)
+    return pcfail(pc, "GenEO preconditioner needs the A matrix to be of MATIS type");
+  pc->has_ops = true;
+  pc->nbDOF = A->nbDOF;
+  pc->nbDOFLoc = A->nbDOFLoc;
+  pc->map.assign(A->map, A->map + A->nbDOFLoc);
+  pc->rowptr.assign(A->local.rowptr, A->local.rowptr + A->nbDOFLoc + 1);
+  const int nnz = pc->rowptr[A->nbDOFLoc];
+  pc->col.assign(A->local.col, A->local.col + nnz);
+  pc->val.assign(A->local.val, A->local.val + nnz);
+  return 0;
+}
+
+PetscErrorCode PCGenEOSetSizes(PC pc, int nbDOF, int nbSubdomainsGlobal) {
+  if (!pc || !pc->ctx) return 1;
+  pc->ctx->N = nbDOF;
+  pc->ctx->nsub_global = nbSubdomainsGlobal;
+  return 0;
+}
+
+PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int n, const int* map, const int* mult, const GeneoCsr* A,
+                                   const GeneoCsr* ADir) {
+  if (!pc || !pc->ctx) return 1;
+  if (!A || A->n != n) return pcfail(pc, "GenEO preconditioner: bad local matrix");
+  if (ADir && ADir->n != n) return pcfail(pc, "GenEO preconditioner: bad dirichlet matrix");
+  GUARD_BEGIN
+  return propagate(pc, pc->ctx->add_subdomain(gid, n, map, mult, A->rowptr, A->col, A->val,
+                                              ADir ? ADir->rowptr : nullptr, ADir ? ADir->col : nullptr,
+                                              ADir ? ADir->val : nullptr));
+  GUARD_END(pc)
+}
+
+PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS mults, const GeneoIS* inters) {
+  (void)inters;  // only its emptiness is used, and only by GenEO-2 (src/geneo.cpp:1139-1148)
+  if (!pc || !pc->ctx) return 1;
+  if (!pc->has_ops) return pcfail(pc, "GenEO preconditioner: PCSetOperators_GenEO must be called first");
+  if (mults.n != pc->nbDOFLoc) return pcfail(pc, "Mismatch in dof mult size and local size");
+  geneo::PC* c = pc->ctx;
+  if (c->N == 0) c->N = pc->nbDOF;
+  if (c->nsub_global == 0) c->nsub_global = c->size;
+  GeneoCsr a{pc->nbDOFLoc, pc->rowptr.data(), pc->col.data(), pc->val.data()};
+  return PCGenEOAddSubdomain(pc, c->rank, pc->nbDOFLoc, pc->map.data(), mults.idx, &a, pcADirLoc);
+}
+
+PetscErrorCode initGenEOPC_c(PC pc, unsigned int nbDOF, unsigned int nbDOFLoc, const int* map, const GeneoCsr* A,
+                             const GeneoCsr* ADir, const double* b_dev, double* x0_dev, const unsigned int* mult) {
+  (void)x0_dev;  // fetched with PCGenEOGetX0 after setup
+  if (!pc || !pc->ctx) return 1;
+  if (!mult) return pcfail(pc, "GenEO preconditioner without DOF multiplicity");
+  geneo::PC* c = pc->ctx;
+  c->N = (int)nbDOF;
+  if (c->nsub_global == 0) c->nsub_global = c->size;
+  std::vector<int> m(mult, mult + nbDOFLoc);
+  pc->b_dev = b_dev;
+  return PCGenEOAddSubdomain(pc, c->rank, (int)nbDOFLoc, map, m.data(), A, ADir);
+}
+
+PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int* owned_gid, int n_halo,
+                              const int* halo_gid, const int* recv_counts, const int* send_counts,
+                              const int* send_idx, GeneoExchangeFn exchange, GeneoAllreduceFn allreduce, void* user,
+                              double* send_dev, double* recv_dev, double* red_dev, int red_capacity) {
+  if (!pc || !pc->ctx) return 1;
+  geneo::PC* c = pc->ctx;
+  if (size < 1 || rank < 0 || rank >= size) return pcfail(pc, "GenEO: bad communicator");
+  c->rank = rank;
+  c->size = size;
+  c->owned.assign(owned_gid, owned_gid + n_owned);
+  c->halo_gid.assign(halo_gid, halo_gid + n_halo);
+  if (size > 1) {
+    c->recv_counts.assign(recv_counts, recv_counts + size);
+    c->send_counts.assign(send_counts, send_counts + size);
+    int ns = 0;
+    for (int q = 0; q < size; ++q) ns += send_counts[q];
+    c->send_idx.assign(send_idx, send_idx + ns);
+  }
+  c->cb_exchange = exchange;
+  c->cb_allreduce = allreduce;
+  c->cb_user = user;
+  c->comm_send = send_dev;
+  c->comm_recv = recv_dev;
+  c->comm_red = red_dev;
+  c->comm_red_cap = red_capacity;
+  return 0;
+}
+
+PetscErrorCode PCGenEOSetRHS(PC pc, const double* b_dev) {
+  if (!pc) return 1;
+  pc->b_dev = b_dev;
+  return 0;
+}
+
+PetscErrorCode PCSetUp_GenEO(PC pc) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  geneo::PC* c = pc->ctx;
+  if (c->nsub_global == 0) c->nsub_global = (int)c->subs.size();
+  return propagate(pc, c->setup(pc->b_dev));
+  GUARD_END(pc)
+}
+PetscErrorCode PCApply_GenEO(PC pc, const double* x, double* y) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  return propagate(pc, pc->ctx->apply(x, y));
+  GUARD_END(pc)
+}
+PetscErrorCode PCGenEOApplyQ(PC pc, const double* x, double* y) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  return propagate(pc, pc->ctx->apply_q(x, y));
+  GUARD_END(pc)
+}
+PetscErrorCode MatMult_GenEO(PC pc, const double* x, double* y) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  return propagate(pc, pc->ctx->matmult(x, y));
+  GUARD_END(pc)
+}
+PetscErrorCode PCGenEOGetX0(PC pc, double* x0_dev) {
+  if (!pc || !pc->ctx || !pc->ctx->x0_dev()) return 1;
+  GUARD_BEGIN
+  bk::d2d(x0_dev, pc->ctx->x0_dev(), sizeof(double) * pc->ctx->n_owned());
+  GUARD_END(pc)
+  return 0;
+}
+PetscErrorCode KSPSolve_GenEO(PC pc, const double* b, double* x, int* its, double* rnorm, int* reason) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  geneo::KspResult r;
+  int rc = pc->ctx->solve(b, x, &r);
+  if (its) *its = r.its;
+  if (rnorm) *rnorm = r.rnorm;
+  if (reason) *reason = r.reason;
+  return propagate(pc, rc);
+  GUARD_END(pc)
+}
+int PCGenEOGetResidualHistory(PC pc, double* hist, int cap) {
+  if (!pc || !pc->ctx) return 0;
+  const auto& h = pc->ctx->residual_history;
+  for (int i = 0; i < (int)h.size() && i < cap; ++i) hist[i] = h[i];
+  return (int)h.size();
+}
+
+PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* o) {
+  if (!pc || !pc->ctx || !o) return 1;
+  const geneo::Info& i = pc->ctx->info;
+  o->estimDimELoc = i.estimDimELoc; o->realDimELoc = i.realDimELoc; o->nicolaidesLoc = i.nicolaidesLoc;
+  o->dimE = i.dimE; o->eig_iterations = i.eig_iterations; o->eig_spmm = i.eig_spmm;
+  o->dls1_iterations = i.dls1_iterations; o->dls1_solves = i.dls1_solves; o->spmv_calls = i.spmv_calls;
+  o->lvl1SetupMinvTimeLoc = i.lvl1SetupMinvTimeLoc; o->lvl2SetupEigTimeLoc = i.lvl2SetupEigTimeLoc;
+  o->lvl2SetupZTimeLoc = i.lvl2SetupZTimeLoc; o->lvl2SetupETimeLoc = i.lvl2SetupETimeLoc;
+  o->lvl1ApplyTimeLoc = i.lvl1ApplyTimeLoc; o->lvl1ApplyScatterTimeLoc = i.lvl1ApplyScatterTimeLoc;
+  o->lvl1ApplyMinvTimeLoc = i.lvl1ApplyMinvTimeLoc; o->lvl1ApplyGatherTimeLoc = i.lvl1ApplyGatherTimeLoc;
+  o->lvl1ApplyPrjFSTimeLoc = i.lvl1ApplyPrjFSTimeLoc; o->lvl2ApplyTimeLoc = i.lvl2ApplyTimeLoc;
+  o->lvl2ApplyZtTimeLoc = i.lvl2ApplyZtTimeLoc; o->lvl2ApplyEinvTimeLoc = i.lvl2ApplyEinvTimeLoc;
+  o->lvl2ApplyZTimeLoc = i.lvl2ApplyZTimeLoc; o->setupTime = i.setupTime; o->solveTime = i.solveTime;
+  return 0;
+}
+static int copy_out(const std::vector<double>& v, double* out, int cap) {
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
+int PCGenEOGetEigenvalues(PC pc, int s, double* vals, int cap) {
+  if (!pc || !pc->ctx || s < 0 || s >= (int)pc->ctx->eigvals.size()) return -1;
+  return copy_out(pc->ctx->eigvals[s], vals, cap);
+}
+int PCGenEOGetCandidates(PC pc, int s, double* vals, int cap) {
+  if (!pc || !pc->ctx || s < 0 || s >= (int)pc->ctx->candidates.size()) return -1;
+  return copy_out(pc->ctx->candidates[s], vals, cap);
+}
+int PCGenEOGetE(PC pc, double* e, int cap) {
+  if (!pc || !pc->ctx) return -1;
+  copy_out(pc->ctx->E, e, cap);
+  return pc->ctx->info.dimE;
+}
+int PCGenEOGetLocalDims(PC pc, int* k, int cap) {
+  if (!pc || !pc->ctx) return -1;
+  const auto& v = pc->ctx->ksub_global;
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) k[i] = v[i];
+  return (int)v.size();
+}
+
+// ---- device helpers ------------------------------------------------------------------------
+const char* GeneoBackendName(void) { return bk::name(); }
+PetscErrorCode GeneoSetStream(void* s) {
+  bk::set_stream(s);
+  return 0;
+}
+void* GeneoDeviceAlloc(size_t bytes) {
+  try {
+    return bk::alloc(bytes);
+  } catch (std::exception& e) {
+    g_global_err = e.what();
+    return nullptr;
+  }
+}
+void GeneoDeviceFree(void* p) { bk::dfree(p); }
+PetscErrorCode GeneoH2D(void* d, const void* s, size_t b) {
+  GUARD_BEGIN
+  bk::h2d(d, s, b);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoD2H(void* d, const void* s, size_t b) {
+  GUARD_BEGIN
+  bk::d2h(d, s, b);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoDeviceSync(void) {
+  GUARD_BEGIN
+  bk::sync();
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+int GeneoSelfTestMFMA(void) {
+  try {
+    return bk::selftest_mfma_f64();
+  } catch (std::exception& e) {
+    g_global_err = e.what();
+    return -1;
+  }
+}
+PetscErrorCode GeneoSetMFMA(int enable) {
+  bk::set_mfma(enable != 0);
+  return 0;
+}
+
+// ---- stand-alone kernels --------------------------------------------------------------------
+PetscErrorCode GeneoSpmvCreate(const GeneoCsr* a, GeneoSpmv* h) {
+  if (!a || !h) return 1;
+  GUARD_BEGIN
+  *h = new _p_GeneoSpmv();
+  (*h)->a = bk::csr_upload(a->n, a->rowptr, a->col, a->val);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoSpmvApply(GeneoSpmv h, const double* x, double* y) {
+  if (!h) return 1;
+  GUARD_BEGIN
+  bk::spmv(h->a, x, y);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x, double* y, int reps, double* ms_avg) {
+  if (!h || reps < 1) return 1;
+  GUARD_BEGIN
+  void* e0 = bk::event_create();
+  void* e1 = bk::event_create();
+  bk::spmv(h->a, x, y);  // warm
+  bk::event_record(e0);
+  for (int i = 0; i < reps; ++i) bk::spmv(h->a, x, y);
+  bk::event_record(e1);
+  const float ms = bk::event_elapsed_ms(e0, e1);
+  if (ms_avg) *ms_avg = (double)ms / reps;
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h) {
+  if (!h || !*h) return 0;
+  bk::csr_free((*h)->a);
+  delete *h;
+  *h = nullptr;
+  return 0;
+}
+PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X, double* Y, int m, const double* pre, const double* post) {
+  if (!h) return 1;
+  GUARD_BEGIN
+  bk::spmm_strided(h->a, X, m, Y, m, m, pre, post);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
+PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* TC, int q,
+                                double* out, int reps, double* ms_avg) {
+  GUARD_BEGIN
+  const int n = suboff[nsub];
+  bk::Chunks c = bk::chunks_upload(nsub, suboff);
+  double* dS = (double*)bk::alloc(sizeof(double) * (size_t)n * p);
+  bk::h2d(dS, S, sizeof(double) * (size_t)n * p);
+  void* e0 = bk::event_create();
+  void* e1 = bk::event_create();
+  if (kind == 0) {
+    double* dT = (double*)bk::alloc(sizeof(double) * (size_t)n * q);
+    double* dG = (double*)bk::alloc(sizeof(double) * (size_t)nsub * p * q);
+    bk::h2d(dT, TC, sizeof(double) * (size_t)n * q);
+    bk::gram(c, dS, p, p, dT, q, q, dG);
+    if (reps > 0) {
+      bk::event_record(e0);
+      for (int i = 0; i < reps; ++i) bk::gram(c, dS, p, p, dT, q, q, dG);
+      bk::event_record(e1);
+      if (ms_avg) *ms_avg = bk::event_elapsed_ms(e0, e1) / reps;
+    }
+    bk::d2h(out, dG, sizeof(double) * (size_t)nsub * p * q);
+    bk::dfree(dT);
+    bk::dfree(dG);
+  } else {
+    double* dC = (double*)bk::alloc(sizeof(double) * (size_t)nsub * p * q);
+    double* dY = (double*)bk::alloc(sizeof(double) * (size_t)n * q);
+    bk::h2d(dC, TC, sizeof(double) * (size_t)nsub * p * q);
+    bk::block_mul(c, dS, p, p, dC, q, dY, q, false);
+    if (reps > 0) {
+      bk::event_record(e0);
+      for (int i = 0; i < reps; ++i) bk::block_mul(c, dS, p, p, dC, q, dY, q, false);
+      bk::event_record(e1);
+      if (ms_avg) *ms_avg = bk::event_elapsed_ms(e0, e1) / reps;
+    }
+    bk::d2h(out, dY, sizeof(double) * (size_t)n * q);
+    bk::dfree(dC);
+    bk::dfree(dY);
+  }
+  bk::dfree(dS);
+  bk::chunks_free(c);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1214 @@
+// GenEO preconditioner core: MI355X-native counterpart of /root/reference/src/geneo.cpp.
+//
+//   reference (PETSc/SLEPc/MUMPS objects)                     here (device-resident, FP64)
+//   ---------------------------------------------------------------------------------------------
+//   MATIS A, VecScatter pcScatCtx      geneo.cpp:156,1850,1881   l2e gather / R^T segmented sums + halo plan
+//   A_Dir = submatrix of assembled A   geneo.cpp:1692-1705       host assembly once (or caller-supplied)
+//   D = 1/multiplicity                 geneo.cpp:965-1000        d_D
+//   KSP(PREONLY)+LU(MUMPS) on A_Dir    geneo.cpp:94-160,1995     batched Jacobi-PCG to dls1_rtol (one CG per subdomain)
+//   EPS arpack shift-invert, GHEP      geneo.cpp:626-744         LOBPCG, Chebyshev-Jacobi preconditioner, MFMA Rayleigh-Ritz
+//   inertia estimate (Sylvester)       geneo.cpp:452-560         replaced: block of cut/nev Ritz pairs, then the tau filter
+//   Nicolaides / empty-Z rule          geneo.cpp:897-944,1305    same tests
+//   Z (MatIS->AIJ), E = Z^T A Z, LU    geneo.cpp:355-450,1028    Z_s column-major per subdomain; E replicated, host Cholesky
+//   applyQ / applyLevel1 / hybrid      geneo.cpp:1435-2098       apply_q / apply
+#include "core.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+
+#include "dense.h"
+
+namespace geneo {
+
+using clk = std::chrono::high_resolution_clock;
+static inline double secs(clk::time_point a, clk::time_point b) {
+  return std::chrono::duration<double>(b - a).count();
+}
+
+// ------------------------------------------------------------------------------------ options
+std::string Options::name() const {
+  std::string n = "geneo" + std::to_string(lvl2);
+  if (hybrid) n += effHybrid ? "E" : "H";
+  std::string l1;
+  if (lvl1ASM) l1 = "ASM";
+  if (lvl1RAS) l1 = "RAS";
+  if (lvl1SRAS) l1 = "SRAS";
+  if (lvl1ORAS) l1 = "ORAS";
+  if (lvl1SRAS && lvl1ORAS) l1 = "SORAS";
+  return n + l1;
+}
+
+static bool to_double(const std::string& s, double& v) {
+  try {
+    size_t pos = 0;
+    v = std::stod(s, &pos);
+    return pos > 0;
+  } catch (...) {
+    return false;
+  }
+}
+static bool to_int(const std::string& s, int& v) {
+  try {
+    size_t pos = 0;
+    v = std::stoi(s, &pos);
+    return pos > 0;
+  } catch (...) {
+    return false;
+  }
+}
+
+std::string parse_option(Options& o, const std::string& key, const std::string& value) {
+  if (key == "-geneo_lvl") {  // geneo.cpp:2344-2370
+    const size_t c = value.find(',');
+    if (c == std::string::npos || value.find(',', c + 1) != std::string::npos) return "invalid option -geneo_lvl";
+    const std::string l1 = value.substr(0, c), l2 = value.substr(c + 1);
+    if (l1 == "ASM") o.lvl1ASM = true;
+    else if (l1 == "RAS") o.lvl1RAS = true;
+    else if (l1 == "SRAS") o.lvl1RAS = o.lvl1SRAS = true;
+    else if (l1 == "ORAS") o.lvl1RAS = o.lvl1ORAS = true;
+    else if (l1 == "SORAS") o.lvl1RAS = o.lvl1SRAS = o.lvl1ORAS = true;
+    else return "invalid option -geneo_lvl, unknown " + l1;
+    if (l2 == "0") { o.lvl2 = 0; }
+    else if (l2 == "1") { o.lvl2 = 1; }
+    else if (l2 == "H1") { o.lvl2 = 1; o.hybrid = true; }
+    else if (l2 == "E1") { o.lvl2 = 1; o.hybrid = true; o.effHybrid = true; }
+    else if (l2 == "2") { o.lvl2 = 2; }
+    else if (l2 == "H2") { o.lvl2 = 2; o.hybrid = true; }
+    else if (l2 == "E2") { o.lvl2 = 2; o.hybrid = true; o.effHybrid = true; }
+    else return "invalid option -geneo_lvl, unknown " + l2;
+    return "";
+  }
+  auto dbl = [&](double& dst) -> std::string {
+    double v;
+    if (!to_double(value, v)) return "invalid option " + key + ", bad " + value;
+    dst = v;
+    return "";
+  };
+  auto integer = [&](int& dst) -> std::string {
+    int v;
+    if (!to_int(value, v)) return "invalid option " + key + ", bad " + value;
+    dst = v;
+    return "";
+  };
+  if (key == "-geneo_optim") return dbl(o.optim);
+  if (key == "-geneo_tau") return dbl(o.tau);
+  if (key == "-geneo_gamma") return dbl(o.gamma);
+  if (key == "-geneo_cut") return integer(o.cut);
+  if (key == "-geneo_cst") { o.cst = true; return ""; }
+  if (key == "-geneo_no_syl") { o.noSyl = true; return ""; }
+  if (key == "-geneo_offload") { o.offload = true; return ""; }
+  if (key == "-els2_eps_tol") return dbl(o.eps_tol);
+  if (key == "-els2_eps_nev") return integer(o.eps_nev);
+  if (key == "-els2_eps_max_it") return integer(o.eps_max_it);
+  if (key == "-els2_eps_block") return integer(o.eps_block);
+  if (key == "-els2_cheb_degree") return integer(o.cheb_degree);
+  if (key == "-els2_cheb_ratio") return dbl(o.cheb_ratio);
+  if (key == "-els2_rr_drop") return dbl(o.rr_drop);
+  if (key == "-els2_eps_seed") { int v; if (!to_int(value, v)) return "bad seed"; o.eps_seed = (uint64_t)v; return ""; }
+  if (key == "-dls1_ksp_rtol") return dbl(o.dls1_rtol);
+  if (key == "-dls1_ksp_max_it") return integer(o.dls1_max_it);
+  if (key == "-dls1_check") return integer(o.dls1_check);
+  if (key == "-ksp_type") {
+    if (value != "cg" && value != "gmres") return "unsupported -ksp_type " + value;
+    o.ksp_type = value;
+    return "";
+  }
+  if (key == "-ksp_rtol") return dbl(o.ksp_rtol);
+  if (key == "-ksp_atol") return dbl(o.ksp_atol);
+  if (key == "-ksp_divtol") return dbl(o.ksp_dtol);
+  if (key == "-ksp_max_it") return integer(o.ksp_max_it);
+  if (key == "-ksp_gmres_restart") return integer(o.ksp_restart);
+  if (key == "-ksp_initial_guess_nonzero") { o.ksp_guess_nonzero = (value != "0" && value != "false"); return ""; }
+  return "unknown option " + key;
+}
+
+std::string validate_options(const Options& o) {  // geneo.cpp:2486-2488
+  if (o.lvl2 >= 1 && o.tau <= 0.) return "GenEO preconditioner: tau must be > 0.";
+  if (o.lvl2 >= 1 && o.tau >= 1.) return "GenEO preconditioner: tau must be < 1.";
+  if (o.lvl2 >= 2 && o.gamma <= 1.) return "GenEO preconditioner: gamma must be > 1.";
+  return "";
+}
+
+// ------------------------------------------------------------------------------------ helpers
+int PC::fail(const std::string& msg) {
+  last_error = msg;
+  return 1;
+}
+PC::~PC() { free_all(); }
+
+void PC::free_all() {
+  bk::csr_free(dirL);
+  // neuE shares rowptr / val / rowblk with neuL: free only its own column array
+  if (neuE.col && neuE.col != neuL.col) bk::dfree(neuE.col);
+  neuE = bk::Csr();
+  bk::csr_free(neuL);
+  if (ch.start) bk::chunks_free(ch);
+  void* ptrs[] = {d_l2e, d_rt_ptr, d_rt_idx, d_send_idx, d_rv_ptr, d_rv_idx, d_rv_tgt, d_D, d_dinv1, d_dinvN, d_xe,
+                  d_ye, d_xL, d_wL, d_cg_r, d_cg_z, d_cg_p, d_cg_q, d_cg_sc, d_t1, d_t2, d_t3, d_x0, d_scal,
+                  d_rvtmp, d_Z, d_zbase, d_ksub, d_zoff, d_subgid, d_yE};
+  for (void* p : ptrs) bk::dfree(p);
+  d_l2e = d_rt_ptr = d_rt_idx = d_send_idx = d_rv_ptr = d_rv_idx = d_rv_tgt = nullptr;
+  d_D = d_dinv1 = d_dinvN = d_xe = d_ye = d_xL = d_wL = nullptr;
+  d_cg_r = d_cg_z = d_cg_p = d_cg_q = d_cg_sc = d_t1 = d_t2 = d_t3 = d_x0 = d_scal = d_rvtmp = nullptr;
+  d_Z = nullptr; d_zbase = nullptr; d_ksub = d_zoff = d_subgid = nullptr; d_yE = nullptr;
+  is_setup = false;
+}
+
+static void copy_csr(HostCsr& dst, int n, const int* rp, const int* col, const double* val) {
+  dst.n = n;
+  dst.rowptr.assign(rp, rp + n + 1);
+  dst.col.assign(col, col + rp[n]);
+  dst.val.assign(val, val + rp[n]);
+}
+
+int PC::add_subdomain(int gid, int n, const int* l2g, const int* mult, const int* nrp, const int* ncol,
+                      const double* nval, const int* drp, const int* dcol, const double* dval) {
+  if (n < 0 || !l2g || !mult || !nrp || !ncol || !nval) return fail("GenEO preconditioner: bad subdomain arguments");
+  Sub s;
+  s.gid = gid;
+  s.l2g.assign(l2g, l2g + n);
+  s.mult.assign(mult, mult + n);
+  for (int i = 1; i < n; ++i)
+    if (s.l2g[i] <= s.l2g[i - 1]) return fail("GenEO preconditioner: local-to-global map must be ascending");
+  for (int i = 0; i < n; ++i)
+    if (s.mult[i] < 1) return fail("GenEO preconditioner bad DOF multiplicity");
+  copy_csr(s.a_neu, n, nrp, ncol, nval);
+  if (drp) copy_csr(s.a_dir, n, drp, dcol, dval);
+  subs.push_back(std::move(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ layout
+int PC::build_layout() {
+  const int ns = (int)subs.size();
+  if (size == 1 && owned.empty()) {
+    owned.resize(N);
+    std::iota(owned.begin(), owned.end(), 0);
+  }
+  const int nown = n_owned();
+  nH = (int)halo_gid.size();
+  nE = nown + nH;
+  suboff.assign(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) suboff[s + 1] = suboff[s] + (int)subs[s].l2g.size();
+  nL = suboff[ns];
+  std::vector<std::pair<int, int>> hmap(nH);
+  for (int i = 0; i < nH; ++i) hmap[i] = {halo_gid[i], i};
+  std::sort(hmap.begin(), hmap.end());
+  const bool ident = (nown == N);
+  std::vector<int> l2e(nL);
+  for (int s = 0; s < ns; ++s)
+    for (size_t i = 0; i < subs[s].l2g.size(); ++i) {
+      const int g = subs[s].l2g[i];
+      int e = -1;
+      if (g < 0 || g >= N) return fail("GenEO preconditioner: global index out of range");
+      if (ident) e = g;
+      else {
+        auto it = std::lower_bound(owned.begin(), owned.end(), g);
+        if (it != owned.end() && *it == g) e = (int)(it - owned.begin());
+        else {
+          auto h = std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(g, -1));
+          if (h == hmap.end() || h->first != g) return fail("GenEO preconditioner: DOF neither owned nor in the halo plan");
+          e = nown + h->second;
+        }
+      }
+      l2e[suboff[s] + i] = e;
+    }
+  // R^T as CSR over the ext space (entries in ascending local index => fixed summation order)
+  std::vector<int> rt_ptr(nE + 1, 0), rt_idx(nL);
+  for (int j = 0; j < nL; ++j) rt_ptr[l2e[j] + 1]++;
+  for (int e = 0; e < nE; ++e) rt_ptr[e + 1] += rt_ptr[e];
+  {
+    std::vector<int> fill(rt_ptr.begin(), rt_ptr.end() - 1);
+    for (int j = 0; j < nL; ++j) rt_idx[fill[l2e[j]]++] = j;
+  }
+  d_l2e = (int*)bk::alloc(sizeof(int) * std::max(1, nL));
+  d_rt_ptr = (int*)bk::alloc(sizeof(int) * (nE + 1));
+  d_rt_idx = (int*)bk::alloc(sizeof(int) * std::max(1, nL));
+  bk::h2d(d_l2e, l2e.data(), sizeof(int) * nL);
+  bk::h2d(d_rt_ptr, rt_ptr.data(), sizeof(int) * (nE + 1));
+  bk::h2d(d_rt_idx, rt_idx.data(), sizeof(int) * nL);
+  // halo plan: forward pack list and reverse-add lists (per owned DOF, ascending recv position)
+  const int nsend = (int)send_idx.size();
+  if (size > 1) {
+    if ((int)recv_counts.size() != size || (int)send_counts.size() != size) return fail("GenEO: bad halo plan");
+    if (std::accumulate(recv_counts.begin(), recv_counts.end(), 0) != nH) return fail("GenEO: bad halo recv counts");
+    if (std::accumulate(send_counts.begin(), send_counts.end(), 0) != nsend) return fail("GenEO: bad halo send counts");
+    if (!cb_exchange || !cb_allreduce || !comm_send || !comm_recv || !comm_red) return fail("GenEO: communicator not set");
+    d_send_idx = (int*)bk::alloc(sizeof(int) * std::max(1, nsend));
+    bk::h2d(d_send_idx, send_idx.data(), sizeof(int) * nsend);
+    std::vector<int> rv_ptr(nown + 1, 0), rv_idx(nsend);
+    for (int k = 0; k < nsend; ++k) {
+      if (send_idx[k] < 0 || send_idx[k] >= nown) return fail("GenEO: bad halo send index");
+      rv_ptr[send_idx[k] + 1]++;
+    }
+    for (int e = 0; e < nown; ++e) rv_ptr[e + 1] += rv_ptr[e];
+    std::vector<int> fill(rv_ptr.begin(), rv_ptr.end() - 1);
+    for (int k = 0; k < nsend; ++k) rv_idx[fill[send_idx[k]]++] = k;
+    d_rv_ptr = (int*)bk::alloc(sizeof(int) * (nown + 1));
+    d_rv_idx = (int*)bk::alloc(sizeof(int) * std::max(1, nsend));
+    bk::h2d(d_rv_ptr, rv_ptr.data(), sizeof(int) * (nown + 1));
+    bk::h2d(d_rv_idx, rv_idx.data(), sizeof(int) * nsend);
+    n_rv = nsend;
+  }
+  ch = bk::chunks_upload(ns, suboff.data());
+  std::vector<int> gids(std::max(1, ns));
+  for (int s = 0; s < ns; ++s) gids[s] = subs[s].gid;
+  d_subgid = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
+  bk::h2d(d_subgid, gids.data(), sizeof(int) * ns);
+  // work vectors
+  auto dv = [](size_t n) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, n)); };
+  d_xe = dv(nE); d_ye = dv(nE); d_xL = dv(nL); d_wL = dv(nL);
+  d_cg_r = dv(nL); d_cg_z = dv(nL); d_cg_p = dv(nL); d_cg_q = dv(nL); d_cg_sc = dv((size_t)8 * std::max(1, ns));
+  d_t1 = dv(nown); d_t2 = dv(nown); d_t3 = dv(nown); d_x0 = dv(nown); d_scal = dv(16);
+  return 0;
+}
+
+// A_Dir,i = R_i (sum_j R_j^T A_Neu,j R_j) R_i^T  -- MatConvert + MatCreateSubMatrices, geneo.cpp:1692-1705
+int PC::ensure_dirichlet() {
+  bool missing = false;
+  for (auto& s : subs)
+    if (s.a_dir.empty()) missing = true;
+  if (!missing) return 0;
+  if (size > 1)
+    return fail("GenEO preconditioner without dirichlet matrix (pass pcADirLoc when subdomains span several ranks)");
+  // assemble the global matrix (COO -> sorted CSR), then extract
+  size_t tot = 0;
+  for (auto& s : subs) tot += s.a_neu.val.size();
+  struct Ent { int64_t key; double v; };
+  std::vector<Ent> coo;
+  coo.reserve(tot);
+  for (auto& s : subs)
+    for (int i = 0; i < s.a_neu.n; ++i)
+      for (int k = s.a_neu.rowptr[i]; k < s.a_neu.rowptr[i + 1]; ++k)
+        coo.push_back({(int64_t)s.l2g[i] * N + s.l2g[s.a_neu.col[k]], s.a_neu.val[k]});
+  std::stable_sort(coo.begin(), coo.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+  std::vector<int64_t> keys;
+  std::vector<double> vals;
+  keys.reserve(coo.size());
+  vals.reserve(coo.size());
+  for (size_t i = 0; i < coo.size();) {
+    size_t j = i;
+    double v = 0.0;
+    while (j < coo.size() && coo[j].key == coo[i].key) v += coo[j++].v;
+    keys.push_back(coo[i].key);
+    vals.push_back(v);
+    i = j;
+  }
+  std::vector<int64_t> rowstart(N + 1, 0);
+  for (int64_t k : keys) rowstart[k / N + 1]++;
+  for (int i = 0; i < N; ++i) rowstart[i + 1] += rowstart[i];
+  std::vector<int> g2l(N, -1);
+  for (auto& s : subs) {
+    if (!s.a_dir.empty()) continue;
+    const int n = (int)s.l2g.size();
+    for (int i = 0; i < n; ++i) g2l[s.l2g[i]] = i;
+    s.a_dir.n = n;
+    s.a_dir.rowptr.assign(n + 1, 0);
+    s.a_dir.col.clear();
+    s.a_dir.val.clear();
+    for (int i = 0; i < n; ++i) {
+      const int g = s.l2g[i];
+      for (int64_t k = rowstart[g]; k < rowstart[g + 1]; ++k) {
+        const int gc = (int)(keys[k] % N);
+        if (g2l[gc] >= 0) {
+          s.a_dir.col.push_back(g2l[gc]);
+          s.a_dir.val.push_back(vals[k]);
+        }
+      }
+      s.a_dir.rowptr[i + 1] = (int)s.a_dir.col.size();
+    }
+    for (int i = 0; i < n; ++i) g2l[s.l2g[i]] = -1;
+  }
+  return 0;
+}
+
+// createRobinMatrix, geneo.cpp:1613-1670: A_Rob = A_Dir + optim * A_Neu[border, border]
+void PC::make_robin(Sub& s, HostCsr& out) const {
+  out = s.a_dir;
+  if (std::fabs(opt.optim) <= DBL_EPSILON) return;
+  const int n = (int)s.l2g.size();
+  std::vector<std::map<int, double>> rows(n);
+  for (int i = 0; i < n; ++i)
+    for (int k = s.a_dir.rowptr[i]; k < s.a_dir.rowptr[i + 1]; ++k) rows[i][s.a_dir.col[k]] += s.a_dir.val[k];
+  for (int i = 0; i < n; ++i) {
+    if (s.mult[i] <= 1) continue;
+    for (int k = s.a_neu.rowptr[i]; k < s.a_neu.rowptr[i + 1]; ++k) {
+      const int c = s.a_neu.col[k];
+      if (s.mult[c] > 1) rows[i][c] += opt.optim * s.a_neu.val[k];
+    }
+  }
+  out.rowptr.assign(n + 1, 0);
+  out.col.clear();
+  out.val.clear();
+  for (int i = 0; i < n; ++i) {
+    for (auto& kv : rows[i]) {
+      out.col.push_back(kv.first);
+      out.val.push_back(kv.second);
+    }
+    out.rowptr[i + 1] = (int)out.col.size();
+  }
+}
+
+static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
+                                const int* colmap /*nullable: L -> ext*/) {
+  const int ns = (int)mats.size();
+  const int n = suboff[ns];
+  std::vector<int> rp(n + 1, 0);
+  size_t nnz = 0;
+  for (auto* m : mats) nnz += m->val.size();
+  std::vector<int> col(nnz);
+  std::vector<double> val(nnz);
+  size_t pos = 0;
+  for (int s = 0; s < ns; ++s) {
+    const HostCsr& m = *mats[s];
+    for (int i = 0; i < m.n; ++i) {
+      for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) {
+        const int cl = suboff[s] + m.col[k];
+        col[pos] = colmap ? colmap[cl] : cl;
+        val[pos] = m.val[k];
+        ++pos;
+      }
+      rp[suboff[s] + i + 1] = (int)pos;
+    }
+  }
+  return bk::csr_upload(n, rp.data(), col.data(), val.data());
+}
+
+// ------------------------------------------------------------------------------------ setup
+int PC::setup(const double* b_dev) {
+  auto t0 = clk::now();
+  if (is_setup) free_all();
+  std::string err = validate_options(opt);
+  if (!err.empty()) return fail(err);
+  if (opt.lvl2 == 2) return fail("GenEO-2 (lvl2 = 2 / SORAS,2) is not built yet on the MI355X path");
+  if (N <= 0) return fail("GenEO preconditioner: empty problem");
+  if (int rc = build_layout()) return rc;
+  if (int rc = ensure_dirichlet()) return rc;
+  const int ns = (int)subs.size();
+  for (auto& s : subs) {
+    if (s.a_neu.n != (int)s.l2g.size() || s.a_dir.n != (int)s.l2g.size())
+      return fail("GenEO preconditioner: local matrix size mismatch");
+  }
+  // level-1 matrices (Dirichlet, or Robin for ORAS: geneo.cpp:137-144)
+  std::vector<HostCsr> rob(ns);
+  std::vector<const HostCsr*> neu(ns), lvl1(ns);
+  for (int s = 0; s < ns; ++s) {
+    neu[s] = &subs[s].a_neu;
+    if (opt.lvl1ORAS) {
+      make_robin(subs[s], rob[s]);
+      lvl1[s] = &rob[s];
+    } else {
+      lvl1[s] = &subs[s].a_dir;
+    }
+  }
+  auto t1 = clk::now();
+  neuL = upload_blockdiag(neu, suboff, nullptr);
+  {  // same matrix with ext-space columns for the MATIS MatMult (shares rowptr / values / row blocks)
+    std::vector<int> l2e(nL);
+    bk::d2h(l2e.data(), d_l2e, sizeof(int) * nL);
+    std::vector<int> colL((size_t)neuL.nnz);
+    bk::d2h(colL.data(), neuL.col, sizeof(int) * (size_t)neuL.nnz);
+    for (auto& c : colL) c = l2e[c];
+    neuE = neuL;
+    neuE.col = (int*)bk::alloc(sizeof(int) * std::max<size_t>(1, colL.size()));
+    bk::h2d(neuE.col, colL.data(), sizeof(int) * colL.size());
+  }
+  dirL = upload_blockdiag(lvl1, suboff, nullptr);
+  // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
+  {
+    std::vector<double> D(std::max(1, nL));
+    for (int s = 0; s < ns; ++s)
+      for (size_t i = 0; i < subs[s].mult.size(); ++i) D[suboff[s] + i] = 1.0 / (double)subs[s].mult[i];
+    d_D = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
+    bk::h2d(d_D, D.data(), sizeof(double) * nL);
+    d_dinv1 = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
+    d_dinvN = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
+    std::vector<double> dg(std::max(1, nL));
+    bk::csr_diag(dirL, d_dinv1);
+    bk::d2h(dg.data(), d_dinv1, sizeof(double) * nL);
+    for (int i = 0; i < nL; ++i) {
+      if (!(dg[i] > 0.0)) return fail("GenEO preconditioner: non-positive diagonal in the local Dirichlet matrix");
+      dg[i] = 1.0 / dg[i];
+    }
+    bk::h2d(d_dinv1, dg.data(), sizeof(double) * nL);
+    bk::csr_diag(neuL, d_dinvN);
+    bk::d2h(dg.data(), d_dinvN, sizeof(double) * nL);
+    // Gershgorin bound of the Jacobi-scaled Neumann matrix (Chebyshev interval)
+    double lmax = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      const HostCsr& m = subs[s].a_neu;
+      for (int i = 0; i < m.n; ++i) {
+        double row = 0.0;
+        for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
+        const double d = dg[suboff[s] + i];
+        if (!(d > 0.0)) return fail("GenEO preconditioner: non-positive diagonal in the local Neumann matrix");
+        lmax = std::max(lmax, row / d);
+      }
+    }
+    cheb_lmax = lmax > 0 ? lmax : 2.0;
+    for (int i = 0; i < nL; ++i) dg[i] = 1.0 / dg[i];
+    bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
+  }
+  bk::sync();
+  info.lvl1SetupMinvTimeLoc = secs(t1, clk::now());
+  is_setup = true;
+  bk::set(d_x0, 0.0, n_owned());
+  if (opt.lvl2) {
+    if (int rc = setup_level2(b_dev)) {
+      is_setup = false;
+      return rc;
+    }
+  }
+  bk::sync();
+  info.setupTime = secs(t0, clk::now());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ R, R^T, comm
+void PC::allreduce(double* dev, int n) {
+  if (size == 1 || n == 0) return;
+  for (int off = 0; off < n; off += comm_red_cap) {
+    const int c = std::min(comm_red_cap, n - off);
+    bk::d2d(comm_red, dev + off, sizeof(double) * c);
+    if (cb_allreduce(cb_user, c)) throw std::runtime_error("GenEO: allreduce callback failed");
+    bk::d2d(dev + off, comm_red, sizeof(double) * c);
+  }
+}
+
+void PC::restrict_to_local(const double* x, double* xL) {
+  if (size == 1) {
+    bk::gather(xL, x, d_l2e, nL);
+    return;
+  }
+  const int nown = n_owned();
+  bk::gather(comm_send, x, d_send_idx, (int)send_idx.size());
+  if (cb_exchange(cb_user, 0)) throw std::runtime_error("GenEO: halo exchange callback failed");
+  bk::copy(d_xe, x, nown);
+  bk::copy(d_xe + nown, comm_recv, nH);
+  bk::gather(xL, d_xe, d_l2e, nL);
+}
+
+void PC::prolong_add(const double* wL, double* y) {
+  const int nown = n_owned();
+  if (size == 1) {
+    bk::segsum(y, wL, d_rt_ptr, d_rt_idx, nown, false);
+    return;
+  }
+  bk::segsum(d_ye, wL, d_rt_ptr, d_rt_idx, nE, false);
+  bk::copy(comm_send, d_ye + nown, nH);
+  if (cb_exchange(cb_user, 1)) throw std::runtime_error("GenEO: halo exchange callback failed");
+  bk::copy(y, d_ye, nown);
+  bk::segsum(y, comm_recv, d_rv_ptr, d_rv_idx, nown, true);
+}
+
+int PC::matmult(const double* x, double* y) {
+  if (!is_setup) return fail("GenEO preconditioner is not set up");
+  info.spmv_calls++;
+  if (size == 1) {
+    bk::spmv(neuE, x, d_wL);
+  } else {
+    const int nown = n_owned();
+    bk::gather(comm_send, x, d_send_idx, (int)send_idx.size());
+    if (cb_exchange(cb_user, 0)) return fail("GenEO: halo exchange callback failed");
+    bk::copy(d_xe, x, nown);
+    bk::copy(d_xe + nown, comm_recv, nH);
+    bk::spmv(neuE, d_xe, d_wL);
+  }
+  prolong_add(d_wL, y);
+  return 0;
+}
+
+// [D] M^-1 [D] on the concatenated local space: one independent Jacobi-PCG per subdomain,
+// all subdomains advanced by the same launches (geneo.cpp:1991-2002 with MUMPS replaced).
+void PC::local_solve(double* wL) {
+  if (opt.lvl1RAS) bk::xmy(wL, wL, d_D, nL);
+  const int ns = (int)subs.size();
+  double* x = d_xL;  // solution
+  bk::cg_start(ch, d_cg_sc, x, d_cg_r, d_cg_z, d_cg_p, wL, d_dinv1);
+  const double tol2 = opt.dls1_rtol * opt.dls1_rtol;
+  std::vector<double> sc((size_t)8 * std::max(1, ns));
+  int it = 0;
+  int parity = 0;
+  const int check = std::max(1, opt.dls1_check);
+  bool done = false;
+  while (!done && it < opt.dls1_max_it) {
+    for (int k = 0; k < check && it < opt.dls1_max_it; ++k, ++it) {
+      bk::spmv(dirL, d_cg_p, d_cg_q);
+      bk::seg_pap(ch, d_cg_p, d_cg_q);
+      bk::cg_update(ch, d_cg_sc, parity, x, d_cg_r, d_cg_z, d_cg_p, d_cg_q, d_dinv1);
+      bk::cg_direction(ch, d_cg_sc, parity, d_cg_p, d_cg_z, tol2);
+      parity ^= 1;
+    }
+    bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
+    done = true;
+    for (int s = 0; s < ns; ++s)
+      if (sc[(size_t)s * 8 + 6] != 0.0) done = false;
+  }
+  info.dls1_iterations += it;
+  info.dls1_solves += 1;
+  if (!done) throw std::runtime_error("GenEO - solve KO: dls1 (KSP_DIVERGED_ITS)");
+  if (opt.lvl1SRAS) bk::xmy(wL, x, d_D, nL);
+  else bk::copy(wL, x, nL);
+}
+
+// yE = E^-1 Z^T x, Z^T x taken from the already restricted xL; replicated host solve
+void PC::coarse_solve_local(const double* xL, double* yE) {
+  auto t0 = clk::now();
+  bk::zt_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, kmax, xL, yE, dimE);
+  allreduce(yE, dimE);
+  bk::d2h(h_yE.data(), yE, sizeof(double) * dimE);
+  auto t1 = clk::now();
+  if (E_chol) dense::cholesky_solve(Efac, dimE, h_yE.data());
+  else dense::lu_solve(Efac, dimE, Epiv, h_yE.data());
+  bk::h2d(yE, h_yE.data(), sizeof(double) * dimE);
+  auto t2 = clk::now();
+  info.lvl2ApplyZtTimeLoc += secs(t0, t1);
+  info.lvl2ApplyEinvTimeLoc += secs(t1, t2);
+}
+
+int PC::apply_q(const double* x, double* y) {
+  if (!is_setup || !opt.lvl2) return fail("GenEO preconditioner: no coarse space");
+  try {
+    restrict_to_local(x, d_xL);
+    coarse_solve_local(d_xL, d_yE);
+    bk::z_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, d_yE, d_wL, false);
+    prolong_add(d_wL, y);
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  return 0;
+}
+
+int PC::apply(const double* x, double* y) {
+  if (!is_setup) return fail("GenEO preconditioner is not set up");
+  const int nown = n_owned();
+  try {
+    auto t0 = clk::now();
+    if (opt.lvl2 && !opt.hybrid) {
+      // y = sum R^T ( Z_s E^-1 Z^T x + [D] M^-1 [D] R x ): one restriction, one prolongation
+      restrict_to_local(x, d_wL);
+      coarse_solve_local(d_wL, d_yE);
+      auto t1 = clk::now();
+      local_solve(d_wL);
+      auto t2 = clk::now();
+      bk::z_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, d_yE, d_wL, true);
+      prolong_add(d_wL, y);
+      info.lvl2ApplyTimeLoc += secs(t0, t1);
+      info.lvl1ApplyMinvTimeLoc += secs(t1, t2);
+      info.lvl1ApplyTimeLoc += secs(t1, clk::now());
+      return 0;
+    }
+    // generic composition (geneo.cpp:2074-2094)
+    bool have_q = false;
+    if (opt.lvl2 && !opt.effHybrid) {  // applyLevel2
+      if (int rc = apply_q(x, y)) return rc;
+      have_q = true;
+      info.lvl2ApplyTimeLoc += secs(t0, clk::now());
+    }
+    auto t1 = clk::now();
+    double* w = d_t1;
+    bk::copy(w, x, nown);
+    if (opt.hybrid && !opt.effHybrid) {  // (I - P^T): w = x - A (Q x), geneo.cpp:1931,1944
+      if (int rc = matmult(y, d_t2)) return rc;
+      bk::axpy(w, -1.0, d_t2, nown);
+    }
+    restrict_to_local(w, d_wL);
+    auto t2 = clk::now();
+    local_solve(d_wL);
+    info.lvl1ApplyMinvTimeLoc += secs(t2, clk::now());
+    prolong_add(d_wL, w);
+    if (opt.hybrid) {  // (I - P): w = w - Q (A w), geneo.cpp:1935-1944
+      if (int rc = matmult(w, d_t2)) return rc;
+      if (int rc = apply_q(d_t2, d_t3)) return rc;
+      bk::axpy(w, -1.0, d_t3, nown);
+    }
+    if (have_q) bk::axpy(y, 1.0, w, nown);
+    else bk::copy(y, w, nown);
+    info.lvl1ApplyTimeLoc += secs(t1, clk::now());
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ level 2
+int PC::setup_level2(const double* b_dev) {
+  const int ns = (int)subs.size();
+  auto t0 = clk::now();
+  eigvals.assign(ns, {});
+  candidates.assign(ns, {});
+  int nmax = 0;
+  for (auto& s : subs) nmax = std::max(nmax, (int)s.l2g.size());
+  int rc = 0;
+  try {
+    if (nmax <= 192) rc = eigen_dense_host();
+    else rc = eigen_lobpcg();
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  if (rc) return rc;
+  bk::sync();
+  auto t1 = clk::now();
+  info.lvl2SetupEigTimeLoc = secs(t0, t1);
+  try {
+    if (int r2 = build_E()) return r2;
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  bk::sync();
+  info.lvl2SetupETimeLoc = secs(t1, clk::now());
+  // initial guess (geneo.cpp:1601-1607)
+  if (opt.effHybrid && b_dev) {
+    if (int r3 = apply_q(b_dev, d_x0)) return r3;
+  }
+  return 0;
+}
+
+// Small subdomains (n <= 192, e.g. the reference's tst/dummy cases): the projected problem IS the
+// full pencil; solved with the same rank-revealing Rayleigh-Ritz routine LOBPCG uses.
+int PC::eigen_dense_host() {
+  const int ns = (int)subs.size();
+  const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
+  std::vector<std::vector<std::vector<double>>> vecs(ns);
+  for (int s = 0; s < ns; ++s) {
+    Sub& sd = subs[s];
+    const int n = (int)sd.l2g.size();
+    std::vector<double> GA((size_t)n * n, 0.0), GB((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int k = sd.a_neu.rowptr[i]; k < sd.a_neu.rowptr[i + 1]; ++k) GA[(size_t)i * n + sd.a_neu.col[k]] += sd.a_neu.val[k];
+    for (int i = 0; i < n; ++i)
+      for (int k = sd.a_dir.rowptr[i]; k < sd.a_dir.rowptr[i + 1]; ++k) {
+        const int c = sd.a_dir.col[k];
+        GB[(size_t)i * n + c] += sd.a_dir.val[k] / ((double)sd.mult[i] * (double)sd.mult[c]);
+      }
+    std::vector<double> th, C;
+    const int r = dense::gen_eig_rr(GA, GB, n, 0, 1e-13, th, C);
+    const int nev = std::min(std::min(nev_try, n), r);
+    // TARGET_MAGNITUDE around 0 (geneo.cpp:638-640): smallest |theta| first
+    std::vector<int> ord(r);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(th[a]) < std::fabs(th[b]); });
+    for (int j = 0; j < nev; ++j) {
+      const int c = ord[j];
+      candidates[s].push_back(th[c]);
+      if (th[c] > opt.tau) continue;  // geneo.cpp:713
+      eigvals[s].push_back(th[c]);
+      std::vector<double> v(n);
+      for (int i = 0; i < n; ++i) v[i] = C[(size_t)i * r + c];
+      vecs[s].push_back(std::move(v));
+    }
+    // Nicolaides (geneo.cpp:897-944)
+    if (!eigvals[s].empty() && *std::min_element(eigvals[s].begin(), eigvals[s].end()) >= DBL_EPSILON) {
+      double num = 0.0, den = 0.0;
+      for (size_t e = 0; e < GA.size(); ++e) { num += GA[e]; den += GB[e]; }
+      if (std::fabs(num / den) <= FLT_EPSILON) {
+        eigvals[s].push_back(0.0);
+        vecs[s].push_back(std::vector<double>(n, 1.0));
+        info.nicolaidesLoc++;
+      }
+    }
+    if (vecs[s].empty()) {  // geneo.cpp:1305-1314
+      eigvals[s].push_back(0.0);
+      vecs[s].push_back(std::vector<double>(n, 1.0));
+      info.nicolaidesLoc++;
+    }
+    info.estimDimELoc += (int)eigvals[s].size();
+  }
+  // Z_s = D .* v (fillZE2L, geneo.cpp:249-286), column-major per subdomain
+  ksub.assign(ns, 0);
+  std::vector<int64_t> zbase(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) {
+    ksub[s] = (int)vecs[s].size();
+    zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
+  }
+  std::vector<double> Z((size_t)std::max<int64_t>(1, zbase[ns]));
+  for (int s = 0; s < ns; ++s) {
+    const int n = (int)subs[s].l2g.size();
+    for (int j = 0; j < ksub[s]; ++j)
+      for (int i = 0; i < n; ++i) Z[zbase[s] + (int64_t)j * n + i] = vecs[s][j][i] / (double)subs[s].mult[i];
+  }
+  d_Z = (double*)bk::alloc(sizeof(double) * Z.size());
+  bk::h2d(d_Z, Z.data(), sizeof(double) * Z.size());
+  d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
+  bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
+  return 0;
+}
+
+// LOBPCG on A_Neu v = lambda (D A_Dir D) v for all local subdomains in lock step.
+// Basis S = [X | P | W] (n_L x 3m row-major).  Per iteration and subdomain:
+//   W = T (A X - B X Lambda)              T = Chebyshev(degree, Jacobi) on A_Neu     (SpMM)
+//   G_A = S^T (A S), G_B = S^T (B S)      FP64-MFMA Gram kernels
+//   rank-revealing Rayleigh-Ritz on host  (3m x 3m)
+//   [X P] <- S C, same for A S, B S       FP64-MFMA block update kernels
+int PC::eigen_lobpcg() {
+  const int ns = (int)subs.size();
+  const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
+  int m = opt.eps_block;
+  if (m <= 0) {
+    const int want = nev_try + std::max(4, nev_try / 4);
+    m = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
+  }
+  if (m != 16 && m != 32 && m != 64) return fail("GenEO: -els2_eps_block must be 16, 32 or 64");
+  if (nev_try > m) return fail("GenEO: -geneo_cut / -els2_eps_nev larger than the LOBPCG block (max 64)");
+  const int p3 = 3 * m;
+  const size_t blk = (size_t)nL * p3;
+  auto dv = [](size_t n) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, n)); };
+  double *S = dv(blk), *AS = dv(blk), *BS = dv(blk), *T = dv(blk), *AT = dv(blk), *BT = dv(blk);
+  double *cr = dv((size_t)nL * m), *cd = dv((size_t)nL * m), *cad = dv((size_t)nL * m);
+  double *dGA = dv((size_t)ns * p3 * p3), *dGB = dv((size_t)ns * p3 * p3), *dC = dv((size_t)ns * p3 * 2 * m);
+  double *dlam = dv((size_t)ns * m), *dnr = dv((size_t)ns * m), *dna = dv((size_t)ns * m), *dnb = dv((size_t)ns * m);
+  std::vector<double*> owned_bufs = {S, AS, BS, T, AT, BT, cr, cd, cad, dGA, dGB, dC, dlam, dnr, dna, dnb};
+  auto cleanup = [&]() { for (double* p : owned_bufs) bk::dfree(p); };
+
+  auto applyA = [&](const double* X, double* Y) { bk::spmm_strided(neuL, X, p3, Y, p3, m, nullptr, nullptr); info.eig_spmm++; };
+  // B = D A_Dir D always uses the true Dirichlet matrix: rebuild if level 1 holds the Robin one
+  bk::Csr dirB = dirL;
+  bool own_dirB = false;
+  if (opt.lvl1ORAS) {
+    std::vector<const HostCsr*> dm(ns);
+    for (int s = 0; s < ns; ++s) dm[s] = &subs[s].a_dir;
+    dirB = upload_blockdiag(dm, suboff, nullptr);
+    own_dirB = true;
+  }
+  auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(dirB, X, p3, Y, p3, m, d_D, d_D); info.eig_spmm++; };
+
+  std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
+  std::vector<double> lam((size_t)ns * m, 0.0), nr((size_t)ns * m), na((size_t)ns * m), nb((size_t)ns * m);
+  std::vector<std::vector<double>> res(ns, std::vector<double>(m, 1.0));
+
+  // ---- start block + Rayleigh-Ritz on X alone
+  bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed);
+  applyA(S, AS);
+  applyB(S, BS);
+  std::vector<char> frozen(ns, 0);
+  auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
+    // Gram blocks of the leading p columns
+    bk::gram(ch, S, p3, p, AS, p3, p, dGA);
+    bk::gram(ch, S, p3, p, BS, p3, p, dGB);
+    bk::d2h(hGA.data(), dGA, sizeof(double) * (size_t)ns * p * p);
+    bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p * p);
+    std::fill(hC.begin(), hC.end(), 0.0);
+    for (int s = 0; s < ns; ++s) {
+      std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
+      std::vector<double> gb(hGB.begin() + (size_t)s * p * p, hGB.begin() + (size_t)(s + 1) * p * p);
+      for (int a = 0; a < p; ++a)
+        for (int b = a + 1; b < p; ++b) {
+          ga[a * p + b] = ga[b * p + a] = 0.5 * (ga[a * p + b] + ga[b * p + a]);
+          gb[a * p + b] = gb[b * p + a] = 0.5 * (gb[a * p + b] + gb[b * p + a]);
+        }
+      double* cs = hC.data() + (size_t)s * p * qout;
+      if (frozen[s]) {  // converged subdomain: keep X, drop P (identity update)
+        for (int j = 0; j < m; ++j) cs[(size_t)j * qout + j] = 1.0;
+        continue;
+      }
+      std::vector<double> th, C;
+      const int r = dense::gen_eig_rr(ga, gb, p, nfix, opt.rr_drop, th, C);
+      for (int j = 0; j < m; ++j) {
+        if (j < r) {
+          lam[(size_t)s * m + j] = th[j];
+          for (int i = 0; i < p; ++i) {
+            const double v = C[(size_t)i * r + j];
+            cs[(size_t)i * qout + j] = v;
+            if (with_p && i >= m) cs[(size_t)i * qout + m + j] = v;  // P = S C with the X rows zeroed
+          }
+        } else {
+          lam[(size_t)s * m + j] = 1e300;  // fewer independent directions than m
+        }
+      }
+    }
+    bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
+    bk::block_mul(ch, S, p3, p, dC, qout, T, p3, false);
+    bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
+    bk::block_mul(ch, BS, p3, p, dC, qout, BT, p3, false);
+    std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT);
+    return 0;
+  };
+  rayleigh_ritz(m, 0, m, false);
+  // P block := 0 (the swap left stale data there)
+  bk::block_axpby(S + m, p3, 0.0, S + m, p3, 0.0, nL, m);
+  bk::block_axpby(AS + m, p3, 0.0, AS + m, p3, 0.0, nL, m);
+  bk::block_axpby(BS + m, p3, 0.0, BS + m, p3, 0.0, nL, m);
+
+  const double tol = opt.eps_tol;
+  const double lmax = cheb_lmax * 1.05, lmin = lmax / std::max(1.5, opt.cheb_ratio);
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  int it = 0;
+  bool all_done = false;
+  std::vector<int> nev_s(ns);
+  for (int s = 0; s < ns; ++s) nev_s[s] = std::min(nev_try, (int)subs[s].l2g.size());
+  for (it = 0; it <= opt.eps_max_it; ++it) {
+    // residual into the W slot, convergence test
+    bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
+    double* W = S + 2 * m;
+    bk::block_residual(ch, AS, p3, BS, p3, dlam, m, cr, m, dnr);
+    bk::block_colnorm(ch, AS, p3, m, dna);
+    bk::block_colnorm(ch, BS, p3, m, dnb);
+    bk::d2h(nr.data(), dnr, sizeof(double) * (size_t)ns * m);
+    bk::d2h(na.data(), dna, sizeof(double) * (size_t)ns * m);
+    bk::d2h(nb.data(), dnb, sizeof(double) * (size_t)ns * m);
+    all_done = true;
+    for (int s = 0; s < ns; ++s) {
+      if (frozen[s]) continue;
+      bool sub_done = true;
+      for (int j = 0; j < m; ++j) {
+        const size_t e = (size_t)s * m + j;
+        const double den = std::sqrt(na[e]) + std::fabs(lam[e]) * std::sqrt(nb[e]);
+        res[s][j] = den > 0 ? std::sqrt(nr[e]) / den : 0.0;
+        if (j < nev_s[s] && lam[e] < 1e299 && !(res[s][j] <= tol)) sub_done = false;
+      }
+      if (sub_done) frozen[s] = 1;
+      else all_done = false;
+    }
+    if (getenv("GENEO_DEBUG")) {
+      fprintf(stderr, "[lobpcg] it %d maxres:", it);
+      for (int s = 0; s < ns; ++s) {
+        double mx = 0.0;
+        for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
+        fprintf(stderr, " %.2e", mx);
+      }
+      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e\n", lam[0], lam[1], lam[nev_s[0] - 1]);
+    }
+    if (all_done || it == opt.eps_max_it) break;
+    // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
+    double rho = 1.0 / sigma;
+    bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
+    bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                       // z = d
+    for (int k = 1; k < opt.cheb_degree; ++k) {
+      bk::spmm_strided(neuL, cd, m, cad, m, m, nullptr, nullptr);         // A d
+      info.eig_spmm++;
+      bk::block_axpby(cr, m, -1.0, cad, m, 1.0, nL, m);                   // r -= A d
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      bk::block_rowscale(cd, m, cr, m, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
+      bk::block_axpby(W, p3, 1.0, cd, m, 1.0, nL, m);                     // z += d
+      rho = rho_new;
+    }
+    applyA(W, AS + 2 * m);
+    applyB(W, BS + 2 * m);
+    rayleigh_ritz(p3, m, 2 * m, true);
+  }
+  info.eig_iterations = it;
+  if (!all_done) {
+    // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).
+    cleanup();
+    if (own_dirB) bk::csr_free(dirB);
+    std::ostringstream msg;
+    msg << "GenEO preconditioner: els2-tau KO (EPS_DIVERGED_ITS after " << it << " LOBPCG iterations)";
+    return fail(msg.str());
+  }
+  // ---- selection (geneo.cpp:709-722), Nicolaides (:897-944), empty-Z rule (:1305-1314)
+  std::vector<int> sel((size_t)ns * m, 0);
+  ksub.assign(ns, 0);
+  double* ones = d_cg_p;
+  double* tmp = d_cg_q;
+  bk::set(ones, 1.0, nL);
+  bk::spmv(neuL, ones, tmp);
+  std::vector<double> numv(ns), denv(ns);
+  bk::seg_dot(ch, tmp, ones, d_cg_sc, 8, 0);
+  bk::xmy(d_cg_r, ones, d_D, nL);
+  bk::spmv(dirB, d_cg_r, tmp);
+  bk::xmy(tmp, tmp, d_D, nL);
+  bk::seg_dot(ch, tmp, ones, d_cg_sc, 8, 1);
+  std::vector<double> sc((size_t)8 * ns);
+  bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
+  for (int s = 0; s < ns; ++s) {
+    int cnt = 0;
+    double minval = 1e300;
+    for (int j = 0; j < nev_s[s]; ++j) {
+      const double l = lam[(size_t)s * m + j];
+      if (l >= 1e299) continue;
+      candidates[s].push_back(l);
+      if (l > opt.tau) continue;
+      sel[(size_t)s * m + cnt++] = j;
+      eigvals[s].push_back(l);
+      minval = std::min(minval, l);
+    }
+    info.estimDimELoc += cnt;
+    if (cnt > 0 && minval >= DBL_EPSILON) {
+      const double ratio = std::fabs(sc[(size_t)s * 8 + 0] / sc[(size_t)s * 8 + 1]);
+      if (ratio <= FLT_EPSILON) {
+        sel[(size_t)s * m + cnt++] = -1;
+        eigvals[s].push_back(0.0);
+        info.nicolaidesLoc++;
+      }
+    }
+    if (cnt == 0) {
+      sel[(size_t)s * m + cnt++] = -1;
+      eigvals[s].push_back(0.0);
+      info.nicolaidesLoc++;
+    }
+    ksub[s] = cnt;
+  }
+  std::vector<int64_t> zbase(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
+  d_Z = (double*)bk::alloc(sizeof(double) * (size_t)std::max<int64_t>(1, zbase[ns]));
+  d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
+  bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
+  int* dsel = (int*)bk::alloc(sizeof(int) * sel.size());
+  int* dks = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
+  bk::h2d(dsel, sel.data(), sizeof(int) * sel.size());
+  bk::h2d(dks, ksub.data(), sizeof(int) * ns);
+  bk::block_extract(ch, S, p3, m, d_D, dsel, dks, d_zbase, d_Z);
+  bk::sync();
+  bk::dfree(dsel);
+  bk::dfree(dks);
+  cleanup();
+  if (own_dirB) bk::csr_free(dirB);
+  return 0;
+}
+
+// E = Z^T A Z (createEEig, geneo.cpp:1028-1095), replicated on every rank, dense factorisation on host.
+int PC::build_E() {
+  const int ns = (int)subs.size();
+  // all_gather of the local sizes (createZE2G, geneo.cpp:360-375) through one all-reduce
+  std::vector<double> kg(std::max(1, nsub_global), 0.0);
+  for (int s = 0; s < ns; ++s) {
+    if (subs[s].gid < 0 || subs[s].gid >= nsub_global) return fail("GenEO: bad global subdomain id");
+    kg[subs[s].gid] = ksub[s];
+  }
+  if (size > 1) {
+    double* dk = (double*)bk::alloc(sizeof(double) * nsub_global);
+    bk::h2d(dk, kg.data(), sizeof(double) * nsub_global);
+    allreduce(dk, nsub_global);
+    bk::d2h(kg.data(), dk, sizeof(double) * nsub_global);
+    bk::dfree(dk);
+  }
+  ksub_global.assign(nsub_global, 0);
+  std::vector<int> zoff_g(nsub_global + 1, 0);
+  for (int g = 0; g < nsub_global; ++g) {
+    ksub_global[g] = (int)std::lround(kg[g]);
+    zoff_g[g + 1] = zoff_g[g] + ksub_global[g];
+  }
+  dimE = zoff_g[nsub_global];
+  info.dimE = dimE;
+  info.realDimELoc = 0;
+  kmax = 0;
+  zoff.assign(ns, 0);
+  for (int s = 0; s < ns; ++s) {
+    zoff[s] = zoff_g[subs[s].gid];
+    kmax = std::max(kmax, ksub[s]);
+    info.realDimELoc += ksub[s];
+  }
+  d_ksub = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
+  d_zoff = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
+  bk::h2d(d_ksub, ksub.data(), sizeof(int) * ns);
+  bk::h2d(d_zoff, zoff.data(), sizeof(int) * ns);
+  d_yE = (double*)bk::alloc(sizeof(double) * std::max(1, dimE));
+  h_yE.assign(std::max(1, dimE), 0.0);
+  // column j of E: Z^T A (Z e_j)
+  E.assign((size_t)dimE * dimE, 0.0);
+  std::vector<double> unit(dimE, 0.0), colv(dimE);
+  const int nown = n_owned();
+  for (int j = 0; j < dimE; ++j) {
+    unit[j] = 1.0;
+    bk::h2d(d_yE, unit.data(), sizeof(double) * dimE);
+    unit[j] = 0.0;
+    bk::z_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, d_yE, d_wL, false);
+    prolong_add(d_wL, d_t1);
+    if (int rc = matmult(d_t1, d_t2)) return rc;
+    restrict_to_local(d_t2, d_xL);
+    bk::zt_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, kmax, d_xL, d_yE, dimE);
+    allreduce(d_yE, dimE);
+    bk::d2h(colv.data(), d_yE, sizeof(double) * dimE);
+    for (int i = 0; i < dimE; ++i) E[(size_t)i * dimE + j] = colv[i];
+  }
+  (void)nown;
+  Efac = E;
+  for (int a = 0; a < dimE; ++a)
+    for (int b = a + 1; b < dimE; ++b) Efac[(size_t)a * dimE + b] = Efac[(size_t)b * dimE + a] =
+        0.5 * (Efac[(size_t)a * dimE + b] + Efac[(size_t)b * dimE + a]);
+  std::vector<double> sym = Efac;
+  E_chol = dense::cholesky(Efac, dimE);
+  if (!E_chol) {
+    Efac = sym;
+    if (!dense::lu_factor(Efac, dimE, Epiv)) return fail("GenEO - solve KO: dcs2 (singular coarse operator E)");
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ Krylov
+double PC::gdot(const double* x, const double* y) {
+  bk::dot(x, y, n_owned(), d_scal);
+  double v = 0.0;
+  if (size > 1) {
+    allreduce(d_scal, 1);
+  }
+  bk::d2h(&v, d_scal, sizeof(double));
+  return v;
+}
+
+// KSPConvergedDefault (PETSc iterativ.c), preconditioned norm
+struct ConvTest {
+  double rtol, atol, dtol, rnorm0 = 0, ttol = 0;
+  int operator()(int it, double rnorm, double snorm_if_guess) {
+    if (it == 0) {
+      rnorm0 = (snorm_if_guess >= 0.0) ? (snorm_if_guess == 0.0 ? rnorm : snorm_if_guess) : rnorm;
+      ttol = std::max(rtol * rnorm0, atol);
+    }
+    if (std::isnan(rnorm) || std::isinf(rnorm)) return -9;
+    if (rnorm <= ttol) return rnorm < atol ? 3 : 2;
+    if (rnorm >= dtol * rnorm0) return -4;
+    return 0;
+  }
+};
+
+// KSPSolve_CG (PETSc cg.c), KSP_NORM_PRECONDITIONED
+int PC::solve_cg(const double* b, double* x, KspResult* res) {
+  const int n = n_owned();
+  auto dv = [&](void) { return (double*)bk::alloc(sizeof(double) * std::max(1, n)); };
+  double *r = dv(), *z = dv(), *p = dv(), *w = dv();
+  auto done = [&](int rc) { bk::dfree(r); bk::dfree(z); bk::dfree(p); bk::dfree(w); return rc; };
+  ConvTest conv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
+  residual_history.clear();
+  if (opt.ksp_guess_nonzero) {
+    if (int rc = matmult(x, r)) return done(rc);
+    bk::axpby(r, 1.0, b, -1.0, n);  // r = b - A x
+  } else {
+    bk::copy(r, b, n);
+  }
+  if (int rc = apply(r, z)) return done(rc);
+  double dp = std::sqrt(gdot(z, z));
+  double snorm = -1.0;
+  if (opt.ksp_guess_nonzero) {
+    if (int rc = apply(b, w)) return done(rc);
+    snorm = std::sqrt(gdot(w, w));
+  }
+  residual_history.push_back(dp);
+  res->its = 0;
+  res->rnorm = dp;
+  res->reason = conv(0, dp, snorm);
+  if (res->reason) return done(0);
+  double betaold = 0.0;
+  for (int i = 0; i < opt.ksp_max_it; ++i) {
+    res->its = i + 1;
+    const double beta = gdot(z, r);
+    if (beta == 0.0) { res->reason = 3; return done(0); }
+    if (i == 0) bk::copy(p, z, n);
+    else bk::axpby(p, 1.0, z, beta / betaold, n);  // p = z + b p
+    if (int rc = matmult(p, w)) return done(rc);
+    const double dpi = gdot(p, w);
+    betaold = beta;
+    if (!(dpi > 0.0)) { res->reason = -8; return done(0); }  // KSP_DIVERGED_INDEFINITE_MAT
+    const double a = beta / dpi;
+    bk::axpy(x, a, p, n);
+    bk::axpy(r, -a, w, n);
+    if (int rc = apply(r, z)) return done(rc);
+    dp = std::sqrt(gdot(z, z));
+    residual_history.push_back(dp);
+    res->rnorm = dp;
+    res->reason = conv(i + 1, dp, -1.0);
+    if (res->reason) return done(0);
+  }
+  res->reason = -3;
+  return done(0);
+}
+
+// KSPSolve_GMRES (PETSc gmres.c): left preconditioning, classical Gram-Schmidt, Givens residual
+int PC::solve_gmres(const double* b, double* x, KspResult* res) {
+  const int n = n_owned();
+  const int m = std::max(1, opt.ksp_restart);
+  std::vector<double*> V;
+  auto dvec = [&]() { return (double*)bk::alloc(sizeof(double) * std::max(1, n)); };
+  double *t = dvec(), *w = dvec();
+  auto done = [&](int rc) {
+    for (double* v : V) bk::dfree(v);
+    bk::dfree(t); bk::dfree(w);
+    return rc;
+  };
+  ConvTest conv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
+  residual_history.clear();
+  res->its = 0;
+  bool first = true;
+  std::vector<double> h((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), yk(m);
+  while (true) {
+    if (V.empty()) V.push_back(dvec());
+    // r = M^-1 (b - A x)
+    if (opt.ksp_guess_nonzero || !first) {
+      if (int rc = matmult(x, t)) return done(rc);
+      bk::axpby(t, 1.0, b, -1.0, n);
+      if (int rc = apply(t, V[0])) return done(rc);
+    } else {
+      if (int rc = apply(b, V[0])) return done(rc);
+    }
+    double rn = std::sqrt(gdot(V[0], V[0]));
+    if (first) {
+      double snorm = -1.0;
+      if (opt.ksp_guess_nonzero) {
+        if (int rc = apply(b, w)) return done(rc);
+        snorm = std::sqrt(gdot(w, w));
+      }
+      residual_history.push_back(rn);
+      res->rnorm = rn;
+      res->reason = conv(0, rn, snorm);
+      if (res->reason) return done(0);
+      first = false;
+    }
+    if (rn == 0.0) { res->reason = 3; return done(0); }
+    bk::axpby(V[0], 1.0 / rn, V[0], 0.0, n);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = rn;
+    int k = 0;
+    int reason = 0;
+    while (k < m && res->its < opt.ksp_max_it) {
+      if ((int)V.size() < k + 2) V.push_back(dvec());
+      if (int rc = matmult(V[k], t)) return done(rc);
+      if (int rc = apply(t, w)) return done(rc);
+      for (int j = 0; j <= k; ++j) h[(size_t)j * m + k] = gdot(V[j], w);  // classical GS: all dots first
+      for (int j = 0; j <= k; ++j) bk::axpy(w, -h[(size_t)j * m + k], V[j], n);
+      const double hn = std::sqrt(gdot(w, w));
+      h[(size_t)(k + 1) * m + k] = hn;
+      if (hn != 0.0) bk::axpby(V[k + 1], 1.0 / hn, w, 0.0, n);
+      for (int j = 0; j < k; ++j) {
+        const double a = h[(size_t)j * m + k], c = h[(size_t)(j + 1) * m + k];
+        h[(size_t)j * m + k] = cs[j] * a + sn[j] * c;
+        h[(size_t)(j + 1) * m + k] = -sn[j] * a + cs[j] * c;
+      }
+      const double den = std::hypot(h[(size_t)k * m + k], h[(size_t)(k + 1) * m + k]);
+      cs[k] = h[(size_t)k * m + k] / den;
+      sn[k] = h[(size_t)(k + 1) * m + k] / den;
+      h[(size_t)k * m + k] = den;
+      h[(size_t)(k + 1) * m + k] = 0.0;
+      g[k + 1] = -sn[k] * g[k];
+      g[k] = cs[k] * g[k];
+      rn = std::fabs(g[k + 1]);
+      ++k;
+      res->its++;
+      residual_history.push_back(rn);
+      res->rnorm = rn;
+      reason = conv(res->its, rn, -1.0);
+      if (reason) break;
+    }
+    for (int i = k - 1; i >= 0; --i) {
+      double s = g[i];
+      for (int j = i + 1; j < k; ++j) s -= h[(size_t)i * m + j] * yk[j];
+      yk[i] = s / h[(size_t)i * m + i];
+    }
+    for (int j = 0; j < k; ++j) bk::axpy(x, yk[j], V[j], n);
+    if (reason) { res->reason = reason; return done(0); }
+    if (res->its >= opt.ksp_max_it) { res->reason = -3; return done(0); }
+  }
+}
+
+int PC::solve(const double* b, double* x, KspResult* res) {
+  if (!is_setup) return fail("GenEO preconditioner is not set up");
+  auto t0 = clk::now();
+  int rc = 0;
+  try {
+    rc = (opt.ksp_type == "cg") ? solve_cg(b, x, res) : solve_gmres(b, x, res);
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  bk::sync();
+  info.solveTime = secs(t0, clk::now());
+  return rc;
+}
+
+}  // namespace geneo

@@ -1,0 +1,162 @@
+// GenEO preconditioner core (host orchestration over the device primitives of backend.h).
+// MI355X-native counterpart of /root/reference/src/geneo.cpp; see DESIGN.md for the map.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+
+namespace geneo {
+
+struct HostCsr {
+  int n = 0;
+  std::vector<int> rowptr, col;
+  std::vector<double> val;
+  bool empty() const { return rowptr.empty(); }
+};
+
+// -geneo_* options: names, defaults and validation follow geneo.cpp:2329-2514 / :2649-2662.
+struct Options {
+  bool lvl1ASM = true, lvl1RAS = false, lvl1SRAS = false, lvl1ORAS = false;
+  int lvl2 = 1;
+  bool hybrid = false, effHybrid = false;
+  double optim = 0.0, tau = 0.1, gamma = 10.0;
+  bool cst = false;
+  int cut = -1;
+  bool noSyl = false, offload = false;
+  // -els2_ : local eigensolver (LOBPCG on the GPU replaces ARPACK shift-invert, geneo.cpp:626-744)
+  double eps_tol = 1e-3;   // EPSSetTolerances default at geneo.cpp:658
+  int eps_nev = 16;        // block target when -geneo_cut is not given (no inertia count on the GPU)
+  int eps_max_it = 500;
+  int eps_block = 0;       // LOBPCG block size m (0 = auto: multiple of 16 >= nev + guard)
+  int cheb_degree = 6;     // Chebyshev-Jacobi preconditioner inside LOBPCG
+  double cheb_ratio = 20.0;
+  double rr_drop = 1e-6;   // pivot threshold of the rank-revealing Rayleigh-Ritz (basis conditioning <= 1/drop)
+  uint64_t eps_seed = 0;
+  // -dls1_ : local "direct" solve replaced by batched Jacobi-PCG driven to a tight tolerance
+  double dls1_rtol = 1e-12;
+  int dls1_max_it = 20000;
+  int dls1_check = 16;     // host convergence poll period (iterations)
+  // Krylov driver (counterpart of the PETSc KSP the reference calls at driver:1240)
+  std::string ksp_type = "gmres";
+  double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e5;
+  int ksp_max_it = 10000, ksp_restart = 30;
+  bool ksp_guess_nonzero = true;   // driver:1348 always sets it
+  std::string name() const;        // buildGenEOName, geneo.cpp:2245-2268
+};
+// returns "" on success, otherwise the error message (same texts as the reference)
+std::string parse_option(Options& o, const std::string& key, const std::string& value);
+std::string validate_options(const Options& o);
+
+struct Info {                 // public counters / timers of geneoContext (hdr/geneo.hpp:96-123)
+  int estimDimELoc = 0, realDimELoc = 0, nicolaidesLoc = 0, dimE = 0;
+  int eig_iterations = 0, eig_spmm = 0;
+  long long dls1_iterations = 0, dls1_solves = 0;
+  double lvl1SetupMinvTimeLoc = 0, lvl2SetupEigTimeLoc = 0, lvl2SetupZTimeLoc = 0, lvl2SetupETimeLoc = 0;
+  double lvl1ApplyTimeLoc = 0, lvl1ApplyScatterTimeLoc = 0, lvl1ApplyMinvTimeLoc = 0, lvl1ApplyGatherTimeLoc = 0;
+  double lvl1ApplyPrjFSTimeLoc = 0, lvl2ApplyTimeLoc = 0, lvl2ApplyZtTimeLoc = 0, lvl2ApplyEinvTimeLoc = 0,
+         lvl2ApplyZTimeLoc = 0;
+  double setupTime = 0, solveTime = 0;
+  long long spmv_calls = 0;
+};
+
+struct KspResult {
+  int its = 0;
+  double rnorm = 0.0;
+  int reason = 0;     // PETSc KSPConvergedReason numbering (2 RTOL, 3 ATOL, -3 ITS, -4 DTOL, -9 NANORINF ...)
+};
+
+typedef int (*exchange_fn)(void* user, int reverse);
+typedef int (*allreduce_fn)(void* user, int n);
+
+class PC {
+ public:
+  Options opt;
+  Info info;
+  std::string last_error;
+
+  // ---- inputs (initGenEOPC / PCGenEOSetup, geneo.cpp:2518-2632) ----------------------------
+  int N = 0;                 // nbDOF
+  int nsub_global = 0;
+  int rank = 0, size = 1;
+  std::vector<int> owned;    // ascending global ids owned by this rank (all of 0..N-1 when size==1)
+  struct Sub {
+    int gid = 0;             // global subdomain id (= MPI rank in the reference)
+    std::vector<int> l2g;    // dofIdxDomLoc (ascending global ids)
+    std::vector<int> mult;   // dofIdxMultLoc
+    HostCsr a_neu, a_dir;    // MATIS local matrix / optional pcADirLoc
+  };
+  std::vector<Sub> subs;
+  // halo plan (size > 1)
+  std::vector<int> halo_gid, recv_counts, send_counts, send_idx;
+  exchange_fn cb_exchange = nullptr;
+  allreduce_fn cb_allreduce = nullptr;
+  void* cb_user = nullptr;
+  double *comm_send = nullptr, *comm_recv = nullptr, *comm_red = nullptr;  // device buffers owned by the caller
+  int comm_red_cap = 0;
+
+  ~PC();
+  int add_subdomain(int gid, int n, const int* l2g, const int* mult, const int* neu_rowptr, const int* neu_col,
+                    const double* neu_val, const int* dir_rowptr, const int* dir_col, const double* dir_val);
+  int setup(const double* b_dev);                       // setUpGenEOPC, geneo.cpp:1672
+  int apply(const double* x_dev, double* y_dev);        // applyGenEOPC, geneo.cpp:2051
+  int apply_q(const double* x_dev, double* y_dev);      // applyQ, geneo.cpp:1435
+  int matmult(const double* x_dev, double* y_dev);      // MatMult(MATIS)
+  int solve(const double* b_dev, double* x_dev, KspResult* res);  // KSPSolve counterpart
+  int n_owned() const { return (int)owned.size(); }
+  const double* x0_dev() const { return d_x0; }
+  // results for parity tests
+  std::vector<std::vector<double>> eigvals;      // per local subdomain: eigenvalues kept in Z
+  std::vector<std::vector<double>> candidates;   // per local subdomain: all converged Ritz values
+  std::vector<double> E;                         // dimE x dimE (row-major)
+  std::vector<int> ksub_global;                  // realDimE per global subdomain
+  std::vector<double> residual_history;
+
+ private:
+  bool is_setup = false;
+  int nL = 0, nE = 0, nH = 0;        // local space, ext (= owned + halo), halo sizes
+  std::vector<int> suboff;
+  bk::Chunks ch;
+  bk::Csr neuL, neuE, dirL;          // block-diagonal CSRs (neuE shares rowptr/val with neuL)
+  int *d_l2e = nullptr, *d_rt_ptr = nullptr, *d_rt_idx = nullptr, *d_send_idx = nullptr;
+  int *d_rv_ptr = nullptr, *d_rv_idx = nullptr, *d_rv_tgt = nullptr;
+  int n_rv = 0;
+  double *d_D = nullptr, *d_dinv1 = nullptr, *d_dinvN = nullptr;
+  double *d_xe = nullptr, *d_ye = nullptr, *d_xL = nullptr, *d_wL = nullptr;
+  double *d_cg_r = nullptr, *d_cg_z = nullptr, *d_cg_p = nullptr, *d_cg_q = nullptr, *d_cg_sc = nullptr;
+  double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_x0 = nullptr, *d_scal = nullptr;
+  double *d_rvtmp = nullptr;
+  // coarse space
+  double* d_Z = nullptr;
+  int64_t* d_zbase = nullptr;
+  int *d_ksub = nullptr, *d_zoff = nullptr, *d_subgid = nullptr;
+  std::vector<int> ksub, zoff;
+  int kmax = 0, dimE = 0;
+  double* d_yE = nullptr;
+  std::vector<double> Efac;
+  std::vector<int> Epiv;
+  bool E_chol = true;
+  std::vector<double> h_yE;
+  double cheb_lmax = 2.0;
+
+  int fail(const std::string& msg);
+  int build_layout();
+  int ensure_dirichlet();
+  void make_robin(Sub& s, HostCsr& out) const;
+  int setup_level2(const double* b_dev);
+  int eigen_dense_host();
+  int eigen_lobpcg();
+  int build_E();
+  void restrict_to_local(const double* x_owned, double* xL);      // R  (applyLevel1Scatter)
+  void prolong_add(const double* wL, double* y_owned);            // sum R^T (applyLevel1Gather)
+  void local_solve(double* wL);                                   // [D] M^-1 [D]
+  void coarse_solve_local(const double* xL, double* yE);          // yE = E^-1 Z^T x (from xL)
+  void allreduce(double* dev, int n);
+  double gdot(const double* x, const double* y);
+  int solve_cg(const double* b, double* x, KspResult* res);
+  int solve_gmres(const double* b, double* x, KspResult* res);
+  void free_all();
+};
+
+}  // namespace geneo

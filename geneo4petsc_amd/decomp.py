@@ -1,0 +1,404 @@
+"""Host-side input producer of the GenEO hot path (numpy, vectorised): the counterpart of the
+reference *driver* between "read / generate the element list" and "hand each rank its domain"
+(src/geneo4PETSc.cpp:196-379 decomposition, :447-494 element weighting, :643-715 local assembly,
+:807-835 right-hand side) and of the three test generators (tst/laplacian, tst/heat, tst/graph).
+
+This is product host code (it never imports the oracle).  tests/test_decomp.py checks it against
+the loop-for-loop oracle restatement and against the reference's tst/dummy goldens.
+
+Elements are stored padded: ``nodes`` (nbElem x W, -1 padded), ``mats`` (nbElem x W*W, row-major
+inside the W x W slot).  All three generators produce 1- and 2-node elements (W = 2).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+
+@dataclass
+class ElementMesh:
+    nbNode: int
+    nodes: np.ndarray   # (nbElem, W) int64, -1 padded
+    mats: np.ndarray    # (nbElem, W*W) float64
+
+    @property
+    def nbElem(self):
+        return self.nodes.shape[0]
+
+    @property
+    def W(self):
+        return self.nodes.shape[1]
+
+
+def mesh_from_lists(nb_node, elem_ptr, elem_idx, elem_mats) -> ElementMesh:
+    """From the reference's (elemPtr, elemIdx, elemSubMat) form (getInput ABI, driver:81-85)."""
+    ne = len(elem_ptr) - 1
+    w = max(elem_ptr[e + 1] - elem_ptr[e] for e in range(ne))
+    nodes = -np.ones((ne, w), dtype=np.int64)
+    mats = np.zeros((ne, w * w))
+    for e in range(ne):
+        s, t = elem_ptr[e], elem_ptr[e + 1]
+        nn = t - s
+        nodes[e, :nn] = elem_idx[s:t]
+        m = np.asarray(elem_mats[e], dtype=np.float64).reshape(nn, nn)
+        blk = np.zeros((w, w))
+        blk[:nn, :nn] = m
+        mats[e] = blk.ravel()
+    return ElementMesh(nb_node, nodes, mats)
+
+
+def read_input_text(text: str, inp_eps: float = 1e-4) -> ElementMesh:
+    """--inpFileA element list: 'dof dof ... [- a11 a12 ...]', '#'/'%' comments (driver:98-194)."""
+    ptr, idx, mats = [0], [], []
+    for raw in text.splitlines():
+        line = raw.lstrip()
+        if not line or line[0] in "%#":
+            continue
+        head, _, tail = line.partition(" - ")
+        dofs = [int(t) for t in head.split() if t.lstrip("+").isdigit()]
+        vals = [float(t) for t in tail.split()] if tail else []
+        n = len(dofs)
+        if not vals:
+            vals = [(1.0 + inp_eps) if i == j else -1.0 / (n - 1) for i in range(n) for j in range(n)]
+        if len(vals) != n * n:
+            raise ValueError("bad matrix in element line: " + raw)
+        idx.extend(dofs)
+        ptr.append(len(idx))
+        mats.append(vals)
+    nb_node = max(idx) + 1
+    if len(set(idx)) != nb_node:
+        raise ValueError("bad node set")
+    return mesh_from_lists(nb_node, ptr, idx, mats)
+
+
+# ------------------------------------------------------------------------------- generators
+def grid_size(size, weak, dim):
+    if dim == 1:
+        return size * weak
+    if dim == 2:
+        return int(math.sqrt(size * size * weak))
+    r = size * size * size * weak
+    c = int(round(r ** (1.0 / 3.0)))
+    while c * c * c > r:
+        c -= 1
+    while (c + 1) ** 3 <= r:
+        c += 1
+    return c
+
+
+def _kappa(interp, alpha, beta, x):
+    x = np.asarray(x, dtype=np.float64)
+    if interp == "quad":
+        return alpha * x * x + beta
+    if interp == "lin":
+        return alpha * x + beta
+    if interp == "minmax":
+        k = np.ones_like(x)
+        k = np.where(x >= beta, alpha, k)
+        k = np.where(x >= 2.0 * beta, 1.0, k)
+        return k
+    return np.ones_like(x)
+
+
+def grid_mesh(size=4, weak=1, dim=3, inp_eps=1e-4, kappa_max=1.0, interp="", heat=False, lbd=1.0, dt=0.1,
+              n: Optional[int] = None) -> ElementMesh:
+    """tst/laplacian (laplacian.cpp:57-188) and tst/heat (heat.cpp:64-261) generators, vectorised.
+
+    1-D edge elements kappa*[[1+eps,-1],[-1,1+eps]] (+ mass/dt for heat) created from the lower
+    endpoint (whose coordinates give kappa = kappa(x) kappa(y) kappa(z)), plus one 1-node Dirichlet
+    element kappa*(1+eps) per node of the face {last coordinate = 0}.  Element order = reference order.
+    """
+    if n is None:
+        n = grid_size(size, weak, dim)
+    d = [n if a < dim else 1 for a in range(3)]
+    xmax = float(n - 1)
+    alpha, beta = 0.0, 1.0
+    if interp == "quad":
+        alpha = (kappa_max - beta) / (xmax * xmax)
+    elif interp == "lin":
+        alpha = (kappa_max - beta) / xmax
+    elif interp == "minmax":
+        alpha, beta = kappa_max, xmax / 3.0
+    i = np.arange(d[0])[None, None, :]
+    j = np.arange(d[1])[None, :, None]
+    k = np.arange(d[2])[:, None, None]
+    cid = (i + d[0] * j + d[0] * d[1] * k)
+    kap = (_kappa(interp, alpha, beta, i) * _kappa(interp, alpha, beta, j) * _kappa(interp, alpha, beta, k))
+    kap = np.broadcast_to(kap, cid.shape)
+    stride = [1, d[0], d[0] * d[1]]
+    coords = [np.broadcast_to(i, cid.shape), np.broadcast_to(j, cid.shape), np.broadcast_to(k, cid.shape)]
+    a_l, b_l, k_l, key_l, bc_l = [], [], [], [], []
+    for ax in range(3):
+        if d[ax] > 1:
+            m = coords[ax] < d[ax] - 1
+            c = cid[m]
+            a_l.append(c); b_l.append(c + stride[ax]); k_l.append(kap[m])
+            key_l.append(c * 6 + 2 * ax + 1); bc_l.append(np.zeros(c.size, dtype=bool))
+    m = coords[dim - 1] == 0                          # Dirichlet face (laplacian.cpp:140-151)
+    c = cid[m]
+    a_l.append(c); b_l.append(-np.ones(c.size, dtype=np.int64)); k_l.append(kap[m])
+    key_l.append(c * 6 + 2 * (dim - 1)); bc_l.append(np.ones(c.size, dtype=bool))
+    a = np.concatenate(a_l); b = np.concatenate(b_l); kk = np.concatenate(k_l)
+    key = np.concatenate(key_l); bc = np.concatenate(bc_l)
+    order = np.argsort(key, kind="stable")
+    a, b, kk, bc = a[order], b[order], kk[order], bc[order]
+    ne = a.size
+    mats = np.zeros((ne, 4))
+    lap_d = (1.0 + inp_eps) * kk
+    if heat:
+        mats[:, 0] = lbd * lap_d + (1.0 / 3.0) / dt
+        mats[:, 1] = np.where(bc, 0.0, lbd * (-kk) + (1.0 / 6.0) / dt)
+        mats[:, 2] = mats[:, 1]
+        mats[:, 3] = np.where(bc, 0.0, lbd * lap_d + (1.0 / 3.0) / dt)
+    else:
+        mats[:, 0] = lap_d
+        mats[:, 1] = np.where(bc, 0.0, -kk)
+        mats[:, 2] = mats[:, 1]
+        mats[:, 3] = np.where(bc, 0.0, lap_d)
+    nodes = np.stack([a, b], axis=1).astype(np.int64)
+    return ElementMesh(int(d[0] * d[1] * d[2]), nodes, mats)
+
+
+def graph_mesh(size=4, level=1, weak=1, inp_eps=1e-4, no_ground=False) -> ElementMesh:
+    """tst/graph generator (graph.cpp:23-208): concentric square blocks, per-level edge weight."""
+    bs = int(math.sqrt(size * weak))
+    a_l, b_l, w_l = [], [], []
+
+    def add(a, b, l):
+        a = np.asarray(a, dtype=np.int64).ravel()
+        b = np.asarray(b, dtype=np.int64).ravel()
+        if b.size == 1:
+            b = np.full(a.size, b[0], dtype=np.int64)
+        a_l.append(a); b_l.append(b); w_l.append(np.full(a.size, float(l)))
+
+    state = {"node": 0 if no_ground else 1}
+    borders = []
+
+    def build_block(central, l):
+        n0 = state["node"]
+        r = np.arange(bs)[:, None]
+        c = np.arange(bs - 1)[None, :]
+        add(n0 + r * bs + c, n0 + r * bs + c + 1, l)               # rows, graph.cpp:49-55
+        last = n0 + bs * bs - 1
+        ii = np.arange(bs)[:, None]
+        jj = np.arange(bs - 1)[None, :]
+        add(last - ii - jj * bs, last - ii - (jj + 1) * bs, l)     # columns, graph.cpp:56-63
+        down = np.sort(last - np.arange(bs))
+        right = np.sort(last - np.arange(bs) * bs)
+        left = np.sort(last - np.arange(bs) * bs - (bs - 1))
+        up = np.sort(last - (bs - 1) * bs - np.arange(bs))
+        borders.append((up, right, down, left))
+        if central:
+            borders.extend([(up, right, down, left)] * 3)
+        state["node"] = n0 + bs * bs
+        if not no_ground:
+            for side in (up, right, down, left):
+                add(side, 0, l)
+
+    build_block(True, 1.0)
+    for l in range(1, level + 1):
+        for _ in range(4):
+            build_block(False, l + 1.0)
+        pairs_h = {0: (1, 0), 1: (2, 1), 2: (3, 2), 3: (0, 3)}
+        for b in range(4):
+            ba = b + 1 if b + 1 < 4 else 0
+            f, t = pairs_h[b]
+            add(borders[4 * l + b][f], borders[4 * l + ba][t], 0.5 * (l + 1.0))
+        pairs_v = {0: (0, 2), 1: (1, 3), 2: (2, 0), 3: (3, 1)}
+        for b in range(4):
+            f, t = pairs_v[b]
+            add(borders[4 * (l - 1) + b][f], borders[4 * l + b][t], 0.5 * (l + 1.0))
+    a = np.concatenate(a_l); b = np.concatenate(b_l); w = np.concatenate(w_l)
+    mats = np.stack([w * (1.0 + inp_eps), -w, -w, w * (1.0 + inp_eps)], axis=1)
+    nb_node = int(max(a.max(), b.max())) + 1
+    return ElementMesh(nb_node, np.stack([a, b], axis=1), mats)
+
+
+# ------------------------------------------------------------------------------- partitions
+def structured_node_partition(n, dim, parts_xyz):
+    """Block partition of the nodes of an n^dim grid (Metis stand-in; Metis is absent offline)."""
+    px, py, pz = parts_xyz
+    d = [n if a < dim else 1 for a in range(3)]
+    bi = (np.arange(d[0]) * px) // d[0]
+    bj = (np.arange(d[1]) * py) // d[1]
+    bk = (np.arange(d[2]) * pz) // d[2]
+    part = bi[None, None, :] + px * (bj[None, :, None] + py * bk[:, None, None])
+    return part.reshape(-1).astype(np.int64)
+
+
+def graph_node_partition(mesh: ElementMesh, nb_part: int):
+    """Greedy BFS-free splitter for unstructured inputs: contiguous node-id ranges of equal size."""
+    return (np.arange(mesh.nbNode) * nb_part // mesh.nbNode).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------- decomposition
+@dataclass
+class Domain:
+    gid: int
+    l2g: np.ndarray            # ascending global node ids (std::set order, driver:1292-1298)
+    mult: np.ndarray           # node multiplicities in the same order
+    a_neu: sp.csr_matrix       # weighted local assembly = MATIS local matrix
+    a_dir: Optional[sp.csr_matrix] = None
+    intersect: Optional[List[np.ndarray]] = None
+
+
+@dataclass
+class Decomposition:
+    nbNode: int
+    nbPart: int
+    node_mult: np.ndarray
+    elem_mult: np.ndarray
+    node_masks: List[np.ndarray]   # per part boolean (nbNode)
+    elem_masks: List[np.ndarray]   # per part boolean (nbElem)
+    domains: List[Domain]
+
+
+def _elem_has(mask_nodes, nodes):
+    valid = nodes >= 0
+    return (mask_nodes[np.where(valid, nodes, 0)] & valid).any(axis=1)
+
+
+def decompose(mesh: ElementMesh, nb_part: int, elem_part=None, node_part=None, metis_dual=False, add_overlap=0,
+              build=True, with_dirichlet=True, parts=None) -> Decomposition:
+    """decompose + addOverlapLayers + buildDomain + fillALoc, vectorised over elements.
+
+    Per part p (driver:312-345): start from the elements of p (dual) or the elements with a node
+    in p (nodal, driver:196-215); each overlap layer adds every element sharing a node with the
+    current element set (driver:244-269); the domain's nodes are the nodes of its elements.
+    Element weights 1/elemMult (driver:473-475); local matrix = sum of weighted element matrices
+    in local (ascending-global) numbering (driver:683-715).
+    ``parts``: build Domain objects only for these part ids (multi-rank hosts).
+    """
+    nodes = mesh.nodes
+    valid = nodes >= 0
+    nn, ne = mesh.nbNode, mesh.nbElem
+    node_mult = np.zeros(nn, dtype=np.int64)
+    elem_mult = np.zeros(ne, dtype=np.int64)
+    nmasks, emasks = [], []
+    for p in range(nb_part):
+        if metis_dual:
+            em = np.asarray(elem_part) == p
+        else:
+            em = _elem_has(np.asarray(node_part) == p, nodes)
+        for _ in range(add_overlap):
+            nm = np.zeros(nn, dtype=bool)
+            nm[nodes[em][valid[em]]] = True
+            em = em | _elem_has(nm, nodes)
+        nm = np.zeros(nn, dtype=bool)
+        nm[nodes[em][valid[em]]] = True
+        node_mult += nm
+        elem_mult += em
+        nmasks.append(nm)
+        emasks.append(em)
+    dec = Decomposition(nn, nb_part, node_mult, elem_mult, nmasks, emasks, [])
+    if not build:
+        return dec
+    w = mesh.W
+    want = range(nb_part) if parts is None else parts
+    g2l = np.full(nn, -1, dtype=np.int64)
+    for p in want:
+        l2g = np.flatnonzero(nmasks[p])
+        g2l[l2g] = np.arange(l2g.size)
+        a_neu = _assemble(mesh, emasks[p], g2l, l2g.size, 1.0 / elem_mult[emasks[p]].astype(np.float64), w)
+        a_dir = None
+        if with_dirichlet:
+            # A_Dir,p = R_p A R_p^T: every global element touching the node set, restricted to it
+            touch = _elem_has(nmasks[p], nodes)
+            a_dir = _assemble(mesh, touch, g2l, l2g.size, None, w)
+        inter = []
+        for q in range(nb_part):
+            if q == p:
+                inter.append(np.zeros(0, dtype=np.int64))
+            else:
+                inter.append(g2l[np.flatnonzero(nmasks[p] & nmasks[q])])
+        dec.domains.append(Domain(p, l2g, node_mult[l2g], a_neu, a_dir, inter))
+        g2l[l2g] = -1
+    return dec
+
+
+def _assemble(mesh, emask, g2l, nloc, weights, w):
+    nodes = mesh.nodes[emask]
+    mats = mesh.mats[emask]
+    if weights is not None:
+        mats = mats * weights[:, None]
+    loc = np.where(nodes >= 0, g2l[np.where(nodes >= 0, nodes, 0)], -1)
+    rows, cols, vals = [], [], []
+    for a in range(w):
+        for b in range(w):
+            ok = (loc[:, a] >= 0) & (loc[:, b] >= 0)
+            rows.append(loc[ok, a]); cols.append(loc[ok, b]); vals.append(mats[ok, a * w + b])
+    m = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(nloc, nloc)).tocsr()
+    m.sort_indices()
+    return m
+
+
+def global_matrix(mesh: ElementMesh) -> sp.csr_matrix:
+    """The assembled operator (what MatConvert(MATIS->AIJ) yields, geneo.cpp:1692)."""
+    ident = np.arange(mesh.nbNode)
+    return _assemble(mesh, np.ones(mesh.nbElem, dtype=bool), ident, mesh.nbNode, None, mesh.W)
+
+
+def rhs_default(a_global: sp.csr_matrix) -> np.ndarray:
+    """b = A (1, 2, ..., N) (driver:820-831)."""
+    return a_global @ np.arange(1.0, a_global.shape[0] + 1.0)
+
+
+def read_b_text(text: str, n: int) -> np.ndarray:
+    """--inpFileB: 'idx [value]' lines (driver:841-858)."""
+    b = np.zeros(n)
+    for raw in text.splitlines():
+        line = raw.lstrip()
+        if not line or line[0] in "%#":
+            continue
+        tok = line.split()
+        b[int(tok[0])] = float(tok[1]) if len(tok) > 1 else 1.0
+    return b
+
+
+# ------------------------------------------------------------------------------- multi-rank plan
+@dataclass
+class RankPlan:
+    """What one rank (one GPU) needs: its subdomains, the DOFs it owns and the halo lists."""
+    rank: int
+    size: int
+    sub_ids: List[int]
+    owned: np.ndarray
+    halo_gid: np.ndarray
+    recv_counts: np.ndarray
+    send_counts: np.ndarray
+    send_idx: np.ndarray
+
+
+def rank_plans(dec: Decomposition, owner_of_node: np.ndarray, sub_rank: np.ndarray, size: int) -> List[RankPlan]:
+    """Ownership + halo plan.  owner_of_node[g] = rank owning DOF g; sub_rank[p] = rank holding
+    subdomain p.  Forward exchange: owner -> every rank whose subdomains contain the DOF."""
+    plans = []
+    needs = []
+    for r in range(size):
+        subs = [p for p in range(dec.nbPart) if sub_rank[p] == r]
+        touched = np.zeros(dec.nbNode, dtype=bool)
+        for p in subs:
+            touched |= dec.node_masks[p]
+        owned = np.flatnonzero(owner_of_node == r)
+        halo = np.flatnonzero(touched & (owner_of_node != r))
+        order = np.lexsort((halo, owner_of_node[halo]))
+        halo = halo[order]
+        recv_counts = np.bincount(owner_of_node[halo], minlength=size).astype(np.int32)
+        needs.append((subs, owned, halo, recv_counts))
+    for r in range(size):
+        subs, owned, halo, recv_counts = needs[r]
+        send_idx, send_counts = [], []
+        for q in range(size):
+            hq = needs[q][2]
+            mine = hq[owner_of_node[hq] == r]          # already ascending inside rank q's segment
+            send_idx.append(np.searchsorted(owned, mine))
+            send_counts.append(mine.size)
+        plans.append(RankPlan(r, size, subs, owned, halo, recv_counts,
+                              np.asarray(send_counts, dtype=np.int32),
+                              np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)))
+    return plans

@@ -1,0 +1,174 @@
+/*
+ * geneo_c.h -- C ABI of libgeneopc, the MI355X-native GenEO preconditioner.
+ *
+ * Drop-in boundary for the PC-shell API of geneo4PETSc:
+ *     reference hdr/geneo_c.h:9   PetscErrorCode createGenEOPC(PC);
+ *     reference hdr/geneo_c.h:10  PetscErrorCode PCGenEOSetup(PC, Mat, IS, IS*);
+ * and for the four callbacks createGenEOPC wires into the PETSc PC (src/geneo.cpp:2717-2720):
+ *     ops->setfromoptions = setUpGenEOPCFromOptions   -> PCSetFromOptions_GenEO
+ *     ops->setup          = setUpGenEOPC              -> PCSetUp_GenEO
+ *     ops->apply          = applyGenEOPC              -> PCApply_GenEO
+ *     ops->destroy        = destroyGenEOPC            -> PCDestroy_GenEO
+ *
+ * PETSc is not available on the GPU box, so the PETSc object types are replaced by plain C
+ * views (pointers and sizes, no PETSc and no torch types).  With PETSc present, the adapter in
+ * INTEGRATION.md pulls these views out of Mat/IS/Vec and forwards to the same entry points.
+ *
+ * Conventions
+ *   - every function returns PetscErrorCode (int): 0 = success; on failure the message is
+ *     available through PCGenEOGetError (the reference aborts through SETERRABORT,
+ *     src/geneo.cpp:74; a library must not abort the host process).
+ *   - host pointers are read during the call and never retained (the reference borrows
+ *     pcA / pcMap / dofIdxMultLoc / intersectLoc, src/geneo.cpp:2221-2230; here they are copied).
+ *   - pointers named *_dev are device (HBM) pointers of this process' GPU; vectors are FP64.
+ *   - one subdomain per rank is the reference's model; this library also accepts several
+ *     subdomains per rank/GPU (PCGenEOAddSubdomain), which is how one MI355X runs a whole
+ *     decomposition.
+ *   - not re-entrant; one context per PC; collective over the ranks given to PCGenEOSetComm.
+ */
+#ifndef __GENEO_C_H
+#define __GENEO_C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int PetscErrorCode;
+typedef struct _p_GeneoPC* PC;         /* stands for PETSc's PC */
+
+typedef struct {                       /* stands for a SEQAIJ Mat: host CSR view */
+  int n;                               /* rows = cols */
+  const int* rowptr;                   /* n + 1 */
+  const int* col;                      /* rowptr[n], local indices, ascending per row */
+  const double* val;
+} GeneoCsr;
+
+typedef struct {                       /* stands for an IS: host index list */
+  int n;
+  const int* idx;
+} GeneoIS;
+
+typedef struct {                       /* stands for the MATIS operator (driver:755-757) */
+  int nbDOF;                           /* global size N */
+  int nbDOFLoc;                        /* local size */
+  const int* map;                      /* local -> global, ascending (driver:1292-1298) */
+  GeneoCsr local;                      /* local (Neumann) matrix, MatISGetLocalMat */
+} GeneoMatIS;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+/* PCCreate + PCSetType(pc,"geneo"): allocates the PC shell, then calls createGenEOPC on it. */
+PetscErrorCode PCCreate_GenEO(PC* pc);
+/* src/geneo.cpp:2639-2728: (re)creates the context with the reference's default parameters. */
+PetscErrorCode createGenEOPC(PC pc);
+/* src/geneo.cpp:2180-2243 */
+PetscErrorCode PCDestroy_GenEO(PC* pc);
+
+/* ---- options (src/geneo.cpp:2329-2514) -------------------------------------------------- */
+/* Parses the -geneo_* options (same spellings, defaults, validation), plus the subset of the
+ * forwarded prefixes this build understands: -els2_eps_{tol,nev,max_it,block,seed},
+ * -els2_cheb_{degree,ratio}, -dls1_ksp_{rtol,max_it}, -ksp_{type,rtol,atol,divtol,max_it},
+ * -ksp_gmres_restart.  Unknown options are ignored, like PETSc with -options_left no. */
+PetscErrorCode PCSetFromOptions_GenEO(PC pc, int argc, const char* const* argv);
+PetscErrorCode PCGenEOSetOption(PC pc, const char* key, const char* value);
+/* buildGenEOName, src/geneo.cpp:2245-2268 ("geneo1ASM", "geneo1HASM", ...) */
+const char* PCGenEOGetName(PC pc);
+const char* PCGenEOGetError(PC pc);
+/* usageGenEO, src/geneo.cpp:2274-2327 */
+const char* usageGenEO_c(void);
+
+/* ---- inputs ----------------------------------------------------------------------------- */
+/* KSPSetOperators(ksp, A, A) with A of type MATIS (required: src/geneo.cpp:1681). */
+PetscErrorCode PCSetOperators_GenEO(PC pc, const GeneoMatIS* A);
+/* hdr/geneo_c.h:10, src/geneo.cpp:2518-2572: one subdomain per rank, operator taken from
+ * PCSetOperators_GenEO; pcADirLoc may be NULL (built from A); dofIntersections may be NULL
+ * (only its emptiness pattern is used, and only by GenEO-2). */
+PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS dofMultiplicities,
+                            const GeneoIS* dofIntersections);
+/* C form of initGenEOPC (hdr/geneo.hpp:30-35, src/geneo.cpp:2591-2632). b_dev / x0_dev may be NULL. */
+PetscErrorCode initGenEOPC_c(PC pc, unsigned int nbDOF, unsigned int nbDOFLoc, const int* map,
+                             const GeneoCsr* A_local, const GeneoCsr* ADirLoc, const double* b_dev,
+                             double* x0_dev, const unsigned int* dofIdxMultLoc);
+
+/* Several subdomains on one rank / GPU (extension; gid = the MPI rank the reference would use). */
+PetscErrorCode PCGenEOSetSizes(PC pc, int nbDOF, int nbSubdomainsGlobal);
+PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int nbDOFLoc, const int* map, const int* multiplicity,
+                                   const GeneoCsr* A_local, const GeneoCsr* ADirLoc);
+
+/* ---- multi-rank plumbing (one process per GPU; the transport is supplied by the host) ----- */
+typedef int (*GeneoExchangeFn)(void* user, int reverse);  /* 0 = forward (owner -> halo), 1 = reverse */
+typedef int (*GeneoAllreduceFn)(void* user, int n);       /* in-place sum of red_dev[0..n) over ranks */
+/* owned_gid: ascending global ids owned by this rank.  halo_gid: ids this rank reads but does not
+ * own, grouped by owner rank (recv_counts[q] ids from rank q).  send_idx: owned-local indices this
+ * rank sends, grouped by destination (send_counts[q]).  The callbacks move send_dev -> recv_dev
+ * with these counts (forward) or with the two count arrays swapped (reverse), on the stream given
+ * to GeneoSetStream.  Buffers are device memory owned by the caller (>= max(sum send, sum recv)). */
+PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int* owned_gid, int n_halo,
+                              const int* halo_gid, const int* recv_counts, const int* send_counts,
+                              const int* send_idx, GeneoExchangeFn exchange, GeneoAllreduceFn allreduce,
+                              void* user, double* send_dev, double* recv_dev, double* red_dev, int red_capacity);
+
+/* ---- PC operations (the PETSc ops table, src/geneo.cpp:2717-2720) ------------------------- */
+PetscErrorCode PCSetUp_GenEO(PC pc);                                   /* setUpGenEOPC :1672 */
+PetscErrorCode PCApply_GenEO(PC pc, const double* x_dev, double* y_dev); /* applyGenEOPC :2051 */
+PetscErrorCode PCGenEOApplyQ(PC pc, const double* x_dev, double* y_dev); /* applyQ :1435 */
+PetscErrorCode MatMult_GenEO(PC pc, const double* x_dev, double* y_dev); /* MatMult on the MATIS A */
+/* initial guess written by setup (src/geneo.cpp:1601-1607): Q b for the efficient hybrid, else 0 */
+PetscErrorCode PCGenEOGetX0(PC pc, double* x0_dev);
+PetscErrorCode PCGenEOSetRHS(PC pc, const double* b_dev);
+
+/* ---- Krylov driver (counterpart of KSPSolve at src/geneo4PETSc.cpp:1240; PETSc's own KSP
+ *      drives PCApply_GenEO instead when PETSc is present) ----------------------------------- */
+PetscErrorCode KSPSolve_GenEO(PC pc, const double* b_dev, double* x_dev, int* its, double* rnorm, int* reason);
+int PCGenEOGetResidualHistory(PC pc, double* hist, int cap);
+
+/* ---- public counters / timers of geneoContext (hdr/geneo.hpp:96-123) ----------------------- */
+typedef struct {
+  int estimDimELoc, realDimELoc, nicolaidesLoc, dimE;
+  int eig_iterations, eig_spmm;
+  long long dls1_iterations, dls1_solves, spmv_calls;
+  double lvl1SetupMinvTimeLoc, lvl2SetupEigTimeLoc, lvl2SetupZTimeLoc, lvl2SetupETimeLoc;
+  double lvl1ApplyTimeLoc, lvl1ApplyScatterTimeLoc, lvl1ApplyMinvTimeLoc, lvl1ApplyGatherTimeLoc;
+  double lvl1ApplyPrjFSTimeLoc, lvl2ApplyTimeLoc, lvl2ApplyZtTimeLoc, lvl2ApplyEinvTimeLoc, lvl2ApplyZTimeLoc;
+  double setupTime, solveTime;
+} GeneoInfo;
+PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* info);
+/* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */
+int PCGenEOGetEigenvalues(PC pc, int local_sub, double* vals, int cap);
+int PCGenEOGetCandidates(PC pc, int local_sub, double* vals, int cap);
+/* coarse operator E (dimE x dimE row-major); returns dimE */
+int PCGenEOGetE(PC pc, double* e, int cap);
+int PCGenEOGetLocalDims(PC pc, int* ksub_global, int cap);
+
+/* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
+const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */
+PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to this stream */
+void* GeneoDeviceAlloc(size_t bytes);
+void GeneoDeviceFree(void* p);
+PetscErrorCode GeneoH2D(void* dst_dev, const void* src, size_t bytes);
+PetscErrorCode GeneoD2H(void* dst, const void* src_dev, size_t bytes);
+PetscErrorCode GeneoDeviceSync(void);
+int GeneoSelfTestMFMA(void);                     /* 0 = f64 MFMA lane maps as assumed */
+PetscErrorCode GeneoSetMFMA(int enable);         /* 0: run the plain-FMA twins of the MFMA kernels (validation) */
+
+/* ---- stand-alone kernels (parity tests and the roofline leg of bench.py) --------------------- */
+typedef struct _p_GeneoSpmv* GeneoSpmv;
+PetscErrorCode GeneoSpmvCreate(const GeneoCsr* a, GeneoSpmv* h);
+PetscErrorCode GeneoSpmvApply(GeneoSpmv h, const double* x_dev, double* y_dev);
+/* average kernel time of `reps` back-to-back launches, HIP events on the library stream */
+PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
+PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h);
+/* Y = post.*(A (pre.*X)), row-major n x m blocks */
+PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, int m, const double* pre_dev,
+                              const double* post_dev);
+/* per-subdomain tall-skinny kernels on host data (suboff: nsub+1 row offsets):
+ *   kind 0: G[s] = S_s^T T_s (p x q)     kind 1: Y_s = S_s C_s (C: nsub x p x q)
+ * GeneoSetMFMA(0) selects the plain-FMA twin.  reps > 0 also times it (HIP events). */
+PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* T_or_C,
+                                int q, double* out, int reps, double* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,322 @@
+// TEST-ONLY serial implementation of csrc/backend.h ("hostsim").
+//
+// Purpose: let the CPU (`-m "not gpu"`) tests exercise the HOST LOGIC of libgeneopc (core.cpp:
+// setup orchestration, LOBPCG driver, batched-CG driver, E assembly, apply modes, Krylov loop,
+// C-ABI argument handling) in a container without a GPU.  It is compiled only by
+// tests/hostsim/build.py into tests/hostsim/libgeneopc_hostsim.so.  The product library
+// (geneo4petsc_amd/csrc -> libgeneopc.so) never contains or links this file, and the
+// geneo4petsc_amd package never loads the hostsim library.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "backend.h"
+
+namespace bk {
+
+static void* g_stream = nullptr;
+const char* name() { return "hostsim"; }
+void set_stream(void* s) { g_stream = s; }
+void* get_stream() { return g_stream; }
+void sync() {}
+
+void* alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
+void dfree(void* p) { free(p); }
+void h2d(void* d, const void* h, size_t b) { if (b) memcpy(d, h, b); }
+void d2h(void* h, const void* d, size_t b) { if (b) memcpy(h, d, b); }
+void d2d(void* d, const void* s, size_t b) { if (b) memmove(d, s, b); }
+void zero(void* d, size_t b) { if (b) memset(d, 0, b); }
+
+Csr csr_upload(int n, const int* rp, const int* col, const double* val) {
+  Csr a;
+  a.n = n;
+  a.nnz = rp[n];
+  a.rowptr = (int*)alloc(sizeof(int) * (n + 1));
+  a.col = (int*)alloc(sizeof(int) * a.nnz);
+  a.val = (double*)alloc(sizeof(double) * a.nnz);
+  memcpy(a.rowptr, rp, sizeof(int) * (n + 1));
+  memcpy(a.col, col, sizeof(int) * a.nnz);
+  memcpy(a.val, val, sizeof(double) * a.nnz);
+  for (int i = 0; i < n; ++i) a.max_row = std::max(a.max_row, rp[i + 1] - rp[i]);
+  return a;
+}
+void csr_free(Csr& a) { dfree(a.rowptr); dfree(a.col); dfree(a.val); a = Csr(); }
+void spmv(const Csr& a, const double* x, double* y) {
+  for (int i = 0; i < a.n; ++i) {
+    double s = 0;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) s += a.val[k] * x[a.col[k]];
+    y[i] = s;
+  }
+}
+void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                  const double* post) {
+  for (int i = 0; i < a.n; ++i)
+    for (int j = 0; j < m; ++j) {
+      double s = 0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        double v = a.val[k];
+        if (pre) v *= pre[a.col[k]];
+        s += v * X[(int64_t)a.col[k] * ldx + j];
+      }
+      if (post) s *= post[i];
+      Y[(int64_t)i * ldy + j] = s;
+    }
+}
+void csr_diag(const Csr& a, double* d) {
+  for (int i = 0; i < a.n; ++i) {
+    double v = 0;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
+      if (a.col[k] == i) v += a.val[k];
+    d[i] = v;
+  }
+}
+void gather(double* out, const double* in, const int* idx, int n) { for (int i = 0; i < n; ++i) out[i] = in[idx[i]]; }
+void gather_mul(double* out, const double* in, const int* idx, const double* d, int n) {
+  for (int i = 0; i < n; ++i) out[i] = in[idx[i]] * d[i];
+}
+void segsum(double* out, const double* in, const int* ptr, const int* idx, int nseg, bool acc) {
+  for (int e = 0; e < nseg; ++e) {
+    double s = 0;
+    for (int k = ptr[e]; k < ptr[e + 1]; ++k) s += in[idx[k]];
+    out[e] = acc ? out[e] + s : s;
+  }
+}
+void set(double* x, double v, int n) { for (int i = 0; i < n; ++i) x[i] = v; }
+void copy(double* y, const double* x, int n) { memmove(y, x, sizeof(double) * (size_t)n); }
+void axpy(double* y, double a, const double* x, int n) { for (int i = 0; i < n; ++i) y[i] += a * x[i]; }
+void axpby(double* y, double a, const double* x, double b, int n) {
+  for (int i = 0; i < n; ++i) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+void xmy(double* y, const double* x, const double* d, int n) { for (int i = 0; i < n; ++i) y[i] = x[i] * d[i]; }
+void axpy_dev(double* y, const double* a, double sign, const double* x, int n) {
+  const double s = sign * a[0];
+  for (int i = 0; i < n; ++i) y[i] += s * x[i];
+}
+void dot(const double* x, const double* y, int n, double* out) {
+  double s = 0;
+  for (int i = 0; i < n; ++i) s += x[i] * y[i];
+  out[0] = s;
+}
+
+Chunks chunks_upload(int nsub, const int* off) {
+  Chunks c;
+  c.nsub = nsub;
+  c.n = off[nsub];
+  std::vector<int> st, ln, sb, sp;
+  sp.push_back(0);
+  for (int s = 0; s < nsub; ++s) {
+    for (int a = off[s]; a < off[s + 1]; a += CHUNK) {
+      st.push_back(a);
+      ln.push_back(std::min(CHUNK, off[s + 1] - a));
+      sb.push_back(s);
+    }
+    sp.push_back((int)st.size());
+  }
+  c.nchunk = (int)st.size();
+  auto dup = [](const std::vector<int>& v) {
+    int* p = (int*)alloc(sizeof(int) * std::max<size_t>(1, v.size()));
+    if (!v.empty()) memcpy(p, v.data(), sizeof(int) * v.size());
+    return p;
+  };
+  c.start = dup(st); c.len = dup(ln); c.sub = dup(sb); c.subptr = dup(sp);
+  c.suboff = (int*)alloc(sizeof(int) * (nsub + 1));
+  memcpy(c.suboff, off, sizeof(int) * (nsub + 1));
+  c.partial = (double*)alloc(sizeof(double) * 4 * std::max(std::max(1, c.nchunk), nsub));
+  return c;
+}
+void chunks_free(Chunks& c) {
+  dfree(c.start); dfree(c.len); dfree(c.sub); dfree(c.subptr); dfree(c.suboff); dfree(c.partial);
+  c = Chunks();
+}
+void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double t = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += x[i] * y[i];
+    out[(int64_t)s * stride + slot] = t;
+  }
+}
+void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, double* p, const double* b,
+              const double* dinv) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double rz = 0, rr = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      x[i] = 0; r[i] = b[i]; z[i] = dinv[i] * r[i]; p[i] = z[i];
+      rz += r[i] * z[i]; rr += r[i] * r[i];
+    }
+    double* q = sc + (int64_t)s * 8;
+    q[0] = q[1] = rz; q[2] = 0; q[3] = rr; q[4] = q[5] = 0; q[6] = rr > 0 ? 1.0 : 0.0; q[7] = rr;
+  }
+}
+void seg_pap(const Chunks& c, const double* p, const double* q) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double t = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += p[i] * q[i];
+    c.partial[s] = t;  // hostsim keeps one partial per subdomain
+  }
+}
+void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, double* z, const double* p,
+               const double* q, const double* dinv) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double* t = sc + (int64_t)s * 8;
+    const double pap = c.partial[s];
+    const double alpha = (t[6] != 0.0 && pap != 0.0) ? t[parity] / pap : 0.0;
+    double nrz = 0, nrr = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      x[i] += alpha * p[i];
+      r[i] -= alpha * q[i];
+      z[i] = dinv[i] * r[i];
+      nrz += r[i] * z[i];
+      nrr += r[i] * r[i];
+    }
+    t[2] = pap; t[4] = alpha;
+    c.partial[c.nsub + 2 * s] = nrz;
+    c.partial[c.nsub + 2 * s + 1] = nrr;
+  }
+}
+void cg_direction(const Chunks& c, double* sc, int parity, double* p, const double* z, double tol2) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double* t = sc + (int64_t)s * 8;
+    const double nrz = c.partial[c.nsub + 2 * s], nrr = c.partial[c.nsub + 2 * s + 1];
+    const double rz = t[parity];
+    const double beta = (t[6] != 0.0 && rz != 0.0) ? nrz / rz : 0.0;
+    if (t[6] != 0.0)
+      for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) p[i] = z[i] + beta * p[i];
+    t[parity ^ 1] = nrz; t[3] = nrr; t[5] = beta;
+    if (t[6] != 0.0 && nrr <= tol2 * t[7]) t[6] = 0.0;
+  }
+}
+
+void gram(const Chunks& c, const double* S, int lds, int p, const double* T, int ldt, int q, double* G) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double* g = G + (int64_t)s * p * q;
+    for (int e = 0; e < p * q; ++e) g[e] = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+      for (int a = 0; a < p; ++a) {
+        const double sv = S[(int64_t)i * lds + a];
+        if (sv == 0.0) continue;
+        for (int b = 0; b < q; ++b) g[a * q + b] += sv * T[(int64_t)i * ldt + b];
+      }
+  }
+}
+void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C, int q, double* Y, int ldy,
+               bool acc) {
+  std::vector<double> row(q);
+  for (int s = 0; s < c.nsub; ++s) {
+    const double* cs = C + (int64_t)s * p * q;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      for (int j = 0; j < q; ++j) row[j] = acc ? Y[(int64_t)i * ldy + j] : 0.0;
+      for (int k = 0; k < p; ++k) {
+        const double sv = S[(int64_t)i * lds + k];
+        if (sv == 0.0) continue;
+        for (int j = 0; j < q; ++j) row[j] += sv * cs[k * q + j];
+      }
+      for (int j = 0; j < q; ++j) Y[(int64_t)i * ldy + j] = row[j];
+    }
+  }
+}
+void block_residual(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam, int m,
+                    double* R, int ldr, double* nrm) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int j = 0; j < m; ++j) {
+      double t = 0;
+      const double lj = lam[(int64_t)s * m + j];
+      for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+        const double v = AX[(int64_t)i * lda + j] - lj * BX[(int64_t)i * ldb + j];
+        R[(int64_t)i * ldr + j] = v;
+        t += v * v;
+      }
+      nrm[(int64_t)s * m + j] = t;
+    }
+}
+void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int j = 0; j < m; ++j) {
+      double t = 0;
+      for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += X[(int64_t)i * ldx + j] * X[(int64_t)i * ldx + j];
+      nrm[(int64_t)s * m + j] = t;
+    }
+}
+void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m) {
+  for (int64_t i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const double xv = a * X[i * ldx + j];
+      Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
+    }
+}
+void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,
+                    int m) {
+  for (int64_t i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const double xv = a * d[i] * X[i * ldx + j];
+      Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
+    }
+}
+void block_colscale(const Chunks& c, double* X, int ldx, int m, const double* cs) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+      for (int j = 0; j < m; ++j) X[(int64_t)i * ldx + j] *= cs[(int64_t)s * m + j];
+}
+static inline double hash_unit(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (gid + 1) + 0xBF58476D1CE4E5B9ull * (row + 1) +
+               0x94D049BB133111EBull * (colj + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+double hash_unit_host(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj) {
+  return hash_unit(seed, gid, row, colj);
+}
+void block_init(const Chunks& c, double* X, int ldx, int m, const int* sub_gid, uint64_t seed) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+      for (int j = 0; j < m; ++j)
+        X[(int64_t)i * ldx + j] =
+            (j == 0) ? 1.0 : hash_unit(seed, (uint64_t)sub_gid[s], (uint64_t)(i - c.suboff[s]), (uint64_t)j);
+}
+void block_extract(const Chunks& c, const double* X, int ldx, int m, const double* d, const int* sel,
+                   const int* ksub, const int64_t* zbase, double* Z) {
+  for (int s = 0; s < c.nsub; ++s) {
+    const int ns = c.suboff[s + 1] - c.suboff[s];
+    for (int j = 0; j < ksub[s]; ++j) {
+      const int src = sel[(int64_t)s * m + j];
+      for (int i = 0; i < ns; ++i) {
+        const int64_t row = c.suboff[s] + i;
+        Z[zbase[s] + (int64_t)j * ns + i] = d[row] * (src < 0 ? 1.0 : X[row * ldx + src]);
+      }
+    }
+  }
+}
+void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff, int kmax,
+              const double* xL, double* yE, int dimE_total) {
+  (void)kmax;
+  for (int e = 0; e < dimE_total; ++e) yE[e] = 0;
+  for (int s = 0; s < c.nsub; ++s) {
+    const int ns = c.suboff[s + 1] - c.suboff[s];
+    for (int j = 0; j < ksub[s]; ++j) {
+      double t = 0;
+      for (int i = 0; i < ns; ++i) t += Z[zbase[s] + (int64_t)j * ns + i] * xL[c.suboff[s] + i];
+      yE[zoff[s] + j] = t;
+    }
+  }
+}
+void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
+             const double* yE, double* wL, bool acc) {
+  for (int s = 0; s < c.nsub; ++s) {
+    const int ns = c.suboff[s + 1] - c.suboff[s];
+    for (int i = 0; i < ns; ++i) {
+      double a = 0;
+      for (int j = 0; j < ksub[s]; ++j) a += Z[zbase[s] + (int64_t)j * ns + i] * yE[zoff[s] + j];
+      wL[c.suboff[s] + i] = acc ? wL[c.suboff[s] + i] + a : a;
+    }
+  }
+}
+void set_mfma(bool) {}
+int selftest_mfma_f64() { return 0; }
+void* event_create() { return nullptr; }
+void event_record(void*) {}
+float event_elapsed_ms(void*, void*) { return 0.f; }
+
+}  // namespace bk
