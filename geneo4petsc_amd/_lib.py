@@ -93,7 +93,7 @@ SYMBOLS = {
 
 def bind(path):
     """dlopen `path` and attach the prototypes of include/geneo_c.h.  Raises if a symbol is missing."""
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype = res

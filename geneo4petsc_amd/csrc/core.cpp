@@ -789,7 +789,10 @@ int PC::eigen_lobpcg() {
   bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed);
   applyA(S, AS);
   applyB(S, BS);
-  std::vector<char> frozen(ns, 0);
+  std::vector<char> frozen(ns, 0), locked((size_t)ns * m, 0);
+  std::vector<double> mask((size_t)ns * m, 1.0);
+  double* dmask = dv((size_t)ns * m);
+  owned_bufs.push_back(dmask);
   auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
     // Gram blocks of the leading p columns
     bk::gram(ch, S, p3, p, AS, p3, p, dGA);
@@ -863,7 +866,10 @@ int PC::eigen_lobpcg() {
         const size_t e = (size_t)s * m + j;
         const double den = std::sqrt(na[e]) + std::fabs(lam[e]) * std::sqrt(nb[e]);
         res[s][j] = den > 0 ? std::sqrt(nr[e]) / den : 0.0;
-        if (j < nev_s[s] && lam[e] < 1e299 && !(res[s][j] <= tol)) sub_done = false;
+        // soft locking: a converged pair stays in X (and in the Rayleigh-Ritz) but no longer
+        // contributes search directions -- its W / P columns would only inject rounding noise
+        if (lam[e] >= 1e299 || res[s][j] <= tol) locked[e] = 1;
+        if (j < nev_s[s] && !locked[e]) sub_done = false;
       }
       if (sub_done) frozen[s] = 1;
       else all_done = false;
@@ -878,6 +884,12 @@ int PC::eigen_lobpcg() {
       fprintf(stderr, " | lam0 %.6e %.6e .. %.6e\n", lam[0], lam[1], lam[nev_s[0] - 1]);
     }
     if (all_done || it == opt.eps_max_it) break;
+    for (size_t e = 0; e < locked.size(); ++e) mask[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+    bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
+    bk::block_colscale(ch, cr, m, m, dmask);
+    bk::block_colscale(ch, S + m, p3, m, dmask);
+    bk::block_colscale(ch, AS + m, p3, m, dmask);
+    bk::block_colscale(ch, BS + m, p3, m, dmask);
     // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
     double rho = 1.0 / sigma;
     bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta

@@ -1,0 +1,87 @@
+"""Shared test-case builders (product host code for the inputs, oracle for the expected values)."""
+import numpy as np
+
+from geneo4petsc_amd import decomp
+from oracle import geneo_oracle as go
+
+
+def grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1, **gen):
+    mesh = decomp.grid_mesh(n=n, dim=dim, **gen)
+    nb = parts[0] * parts[1] * parts[2]
+    dec = decomp.decompose(mesh, nb, None, decomp.structured_node_partition(n, dim, parts), False, overlap)
+    a = decomp.global_matrix(mesh)
+    b = decomp.rhs_default(a)
+    return mesh, dec, a, b
+
+
+def oracle_for(mesh, dec, argv, b):
+    subs = [go.Subdomain(d.l2g, d.a_neu, d.mult, d.intersect) for d in dec.domains]
+    return go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv)).setup(b)
+
+
+def ksp_args(argv):
+    out = dict(rtol=1e-5, atol=1e-50, max_it=10000, restart=30)
+    ksp = "gmres"
+    for i, a in enumerate(argv):
+        if a == "-ksp_type":
+            ksp = argv[i + 1]
+        if a == "-ksp_rtol":
+            out["rtol"] = float(argv[i + 1])
+        if a == "-ksp_atol":
+            out["atol"] = float(argv[i + 1])
+        if a == "-ksp_gmres_restart":
+            out["restart"] = int(argv[i + 1])
+    if ksp == "cg":
+        out.pop("restart")
+    return ksp, out
+
+
+def run_pc(lib, mesh, dec, argv, b, with_dir=True):
+    from geneo4petsc_amd.pc import GenEOPC
+    pc = GenEOPC(lib)
+    pc.set_from_options(argv)
+    pc.set_sizes(mesh.nbNode, len(dec.domains))
+    for d in dec.domains:
+        pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir if with_dir else None)
+    pc.setup(b)
+    return pc
+
+
+def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, xtol=1e-8, aptol=1e-9):
+    """Full parity check of one configuration: integer outputs exact, floats within tolerance."""
+    mesh, dec, a, b = grid_case(n=n, parts=parts, overlap=overlap, **(gen or {}))
+    pc = run_pc(lib, mesh, dec, argv, b, with_dir)
+    orc = oracle_for(mesh, dec, argv, b)
+    ksp, kw = ksp_args(argv)
+    res = go.solve(orc, b, ksp, **kw)
+    x, its, rnorm, reason = pc.solve(b)
+    info = pc.info()
+    assert pc.name == orc.o.name
+    assert reason == res.reason, (reason, res.reason)
+    # Iteration count: identical to the oracle's.  One documented exception (DESIGN.md "Parity"):
+    # CG in finite precision becomes chaotic once its first Ritz value has converged
+    # (Greenbaum/Strakos) -- the oracle's OWN count moves by +-1 when b is perturbed by 1e-14
+    # (tests/test_oracle_eig.py::test_cg_count_is_rounding_sensitive), so for long CG runs the count
+    # is only defined up to that band.  There the bar is: same operator (checked below to 1e-9),
+    # same first iterations of the residual history to 1e-8, and a count within +-2.  GMRES: exact.
+    if its != res.its:
+        assert ksp == "cg", "iteration count differs: %d vs oracle %d" % (its, res.its)
+        assert abs(its - res.its) <= 2, "iteration count differs: %d vs oracle %d" % (its, res.its)
+        k = min(8, len(res.history), len(pc.residual_history()))
+        np.testing.assert_allclose(pc.residual_history()[:k], res.history[:k], rtol=1e-8)
+    if orc.o.lvl2:
+        assert list(pc.local_dims()) == orc.realDimELoc                                  # integer selection
+        assert info["nicolaidesLoc"] == sum(orc.nicolaidesLoc)
+        assert info["dimE"] == orc.dimE
+        for s in range(len(dec.domains)):
+            ev = np.sort(pc.eigenvalues(s))
+            np.testing.assert_allclose(ev, np.sort(orc.eigvals[s]), rtol=1e-10, atol=1e-13)  # 1e-10 relative
+        q1, q2 = pc.apply_q(b), orc.apply_q(b)
+        assert np.linalg.norm(q1 - q2) <= aptol * np.linalg.norm(q2)
+    y1, y2 = pc.apply(b), orc.apply(b)
+    assert np.linalg.norm(y1 - y2) <= aptol * np.linalg.norm(y2)
+    m1, m2 = pc.matmult(b), orc.matmult(b)
+    assert np.linalg.norm(m1 - m2) <= 1e-13 * np.linalg.norm(m2)
+    assert np.linalg.norm(x - res.x) <= xtol * np.linalg.norm(res.x)
+    pc.destroy()
+    return its, info

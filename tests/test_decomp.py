@@ -1,0 +1,102 @@
+"""Product host code (geneo4petsc_amd/decomp.py, vectorised) against the loop-for-loop oracle
+restatement of the reference driver and against the reference's tst/dummy goldens."""
+import numpy as np
+import pytest
+
+import dummy_cases as dc
+from geneo4petsc_amd import decomp
+from oracle import driver_oracle as drv
+
+
+def _same(a, b, tol=1e-13):
+    d = (a - b)
+    return a.shape == b.shape and (abs(d).max() if d.nnz else 0.0) <= tol
+
+
+@pytest.mark.parametrize("dim,n,parts,ov,kw", [
+    (3, 6, (2, 2, 1), 1, dict(kappa_max=2.0, interp="lin")),
+    (2, 9, (3, 2, 1), 2, dict()),
+    (3, 5, (2, 1, 2), 0, dict(heat=True, kappa_max=3.0, interp="minmax")),
+    (1, 12, (3, 1, 1), 1, dict(kappa_max=2.0, interp="quad")),
+    (3, 7, (2, 2, 2), 2, dict(heat=True, lbd=2.0, dt=0.5)),
+])
+def test_grid_generators_and_decomposition(dim, n, parts, ov, kw):
+    om = drv.grid_input(size=n, dim=dim, **kw)
+    pm = decomp.grid_mesh(size=n, dim=dim, **kw)
+    assert (om.nbElem, om.nbNode) == (pm.nbElem, pm.nbNode)
+    for e in range(om.nbElem):                       # same elements, same ORDER, same matrices
+        s, t = om.elemPtr[e], om.elemPtr[e + 1]
+        assert list(pm.nodes[e][:t - s]) == om.elemIdx[s:t]
+        nn = t - s
+        np.testing.assert_allclose(pm.mats[e].reshape(2, 2)[:nn, :nn].ravel(), om.elemSubMat[e], rtol=1e-15)
+    nb = parts[0] * parts[1] * parts[2]
+    npart = drv.structured_node_partition(drv.grid_size(n, 1, dim), dim, parts)
+    assert (npart == decomp.structured_node_partition(drv.grid_size(n, 1, dim), dim, parts)).all()
+    od = drv.decompose(om, nb, None, list(npart), False, ov)
+    pd = decomp.decompose(pm, nb, None, npart, False, ov)
+    a = drv.global_matrix(od, [drv.assemble_local(om, od, p) for p in range(nb)], om.nbNode)
+    assert _same(a, decomp.global_matrix(pm))
+    assert (od.nodeIdxMult == pd.node_mult).all() and (od.elemIdxMult == pd.elem_mult).all()
+    for p in range(nb):
+        assert (od.nodeIdxDom[p] == pd.domains[p].l2g).all()
+        assert (od.nodeIdxMult[od.nodeIdxDom[p]] == pd.domains[p].mult).all()
+        assert _same(drv.assemble_local(om, od, p), pd.domains[p].a_neu)
+        l = od.nodeIdxDom[p]
+        assert _same(a[l][:, l].tocsr(), pd.domains[p].a_dir)
+        for q in range(nb):
+            assert (od.intersectDom[p][q] == pd.domains[p].intersect[q]).all()
+
+
+@pytest.mark.parametrize("kw", [dict(size=9, level=2), dict(size=16, level=1, no_ground=True),
+                                dict(size=4, level=3, no_ground=True)])
+def test_graph_generator(kw):
+    om, pm = drv.graph_input(**kw), decomp.graph_mesh(**kw)
+    assert (om.nbElem, om.nbNode) == (pm.nbElem, pm.nbNode)
+    for e in range(om.nbElem):
+        assert list(pm.nodes[e]) == om.elemIdx[2 * e:2 * e + 2]
+        np.testing.assert_allclose(pm.mats[e], om.elemSubMat[e], rtol=1e-15)
+
+
+def test_dual_partition_matches_oracle():
+    om = drv.grid_input(size=5, dim=2)
+    pm = decomp.grid_mesh(size=5, dim=2)
+    rng = np.random.default_rng(0)
+    ep = rng.integers(0, 3, size=om.nbElem)
+    od = drv.decompose(om, 3, list(ep), None, True, 1)
+    pd = decomp.decompose(pm, 3, ep, None, True, 1)
+    for p in range(3):
+        assert (od.nodeIdxDom[p] == pd.domains[p].l2g).all()
+        assert _same(drv.assemble_local(om, od, p), pd.domains[p].a_neu)
+
+
+@pytest.mark.parametrize("rec", dc.geneo_refs()[::7], ids=lambda r: r["file"][:-4])
+def test_dummy_goldens_through_product_decomposition(rec):
+    """Reference goldens: the product's reader + decomposition + weighted assembly reproduce the printed
+    per-rank MATIS matrices, nnz count and RHS."""
+    d = dc.load()
+    mesh = decomp.read_input_text(d["inputs"][rec["input"] + ".inp"], rec["inpEps"])
+    ep, npart = dc.partition_for(rec)
+    dec = decomp.decompose(mesh, 2, ep, npart, rec["metis"] == "dual", rec["overlap"])
+    for p in range(2):
+        assert dc.same_rows(dc.rows_of(dec.domains[p].a_neu), rec["mats"][p])
+    nnz = sum(int(dom.a_neu.indptr[-1]) for dom in dec.domains)
+    assert ("nnz coefs %d," % nnz) in rec["info"][0]
+    a = decomp.global_matrix(mesh)
+    b = decomp.read_b_text(d["inputs"]["B.inp"], mesh.nbNode) if rec["use_b_file"] else decomp.rhs_default(a)
+    np.testing.assert_allclose(b, rec["b"], rtol=1e-6)
+
+
+def test_rank_plans_cover_every_halo():
+    mesh = decomp.grid_mesh(n=8, dim=3)
+    npart = decomp.structured_node_partition(8, 3, (2, 2, 1))
+    dec = decomp.decompose(mesh, 4, None, npart, False, 1, build=False)
+    sub_rank = np.array([0, 0, 1, 1])
+    owner = sub_rank[npart]
+    plans = decomp.rank_plans(dec, owner, sub_rank, 2)
+    for pl in plans:
+        assert (owner[pl.owned] == pl.rank).all() and (owner[pl.halo_gid] != pl.rank).all()
+        assert pl.recv_counts.sum() == pl.halo_gid.size and pl.send_counts.sum() == pl.send_idx.size
+    # what rank 0 sends to rank 1 is exactly what rank 1 expects from rank 0, in the same order
+    s01 = plans[0].owned[plans[0].send_idx[plans[0].send_counts[:1].sum():plans[0].send_counts[:2].sum()]]
+    r10 = plans[1].halo_gid[:plans[1].recv_counts[0]]
+    assert (s01 == r10).all()

@@ -1,0 +1,91 @@
+"""-m gpu: the GenEO hot path on the MI355X (through the C ABI) against the oracle.
+
+Bars (BASELINE.json north_star): Krylov iteration counts identical; eigenvalues within 1e-10
+relative; number of retained eigenvectors / Nicolaides count exact; solution within 1e-8 of the
+oracle's iterate at the same tolerance and within 1e-10 relative at ksp_rtol 1e-12.
+"""
+import numpy as np
+import pytest
+
+import cases
+import dummy_cases as dc
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = ["-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from geneo4petsc_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("lvl,ksp,overlap", [("ASM,0", "cg", 1), ("ASM,1", "cg", 1), ("ASM,1", "gmres", 2),
+                                             ("RAS,1", "gmres", 1), ("SRAS,1", "cg", 2), ("ASM,H1", "cg", 1),
+                                             ("ASM,E1", "gmres", 1), ("SRAS,H1", "cg", 2), ("SRAS,1", "cg", 1),
+                                             ("RAS,H1", "gmres", 2), ("ORAS,1", "gmres", 1)])
+def test_modes_match_oracle(lib, lvl, ksp, overlap):
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp] + TIGHT
+    cases.compare_with_oracle(lib, 12, (2, 2, 2), overlap, argv)
+
+
+def test_dirichlet_built_by_library(lib):
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "cg"] + TIGHT
+    cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv, with_dir=False)
+
+
+def test_variable_kappa_and_uneven_parts(lib):
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.15", "-geneo_cut", "12", "-ksp_type", "cg"] + TIGHT
+    cases.compare_with_oracle(lib, 14, (3, 2, 1), 1, argv, gen=dict(kappa_max=4.0, interp="lin"))
+
+
+def test_heat_high_contrast(lib):
+    """BASELINE config 4: GenEO coarse space vs plain ASM on the anisotropic/high-contrast heat operator."""
+    gen = dict(heat=True, kappa_max=100.0, interp="minmax")
+    a0 = ["-geneo_lvl", "ASM,0", "-ksp_type", "cg"] + TIGHT
+    a1 = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.015", "-geneo_cut", "12", "-ksp_type", "cg"] + TIGHT
+    its0, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a0, gen=gen)
+    its1, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a1, gen=gen)
+    assert its1 <= its0
+
+
+def test_solution_1e10(lib):
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "cg",
+            "-els2_eps_tol", "1e-9", "-ksp_rtol", "1e-12", "-ksp_atol", "1e-50"]
+    mesh, dec, a, b = cases.grid_case(12, 3, (2, 2, 2), 1)
+    pc = cases.run_pc(lib, mesh, dec, argv, b)
+    x, its, rnorm, reason = pc.solve(b)
+    exact = np.arange(1.0, mesh.nbNode + 1.0)
+    assert np.linalg.norm(x - exact) <= 1e-10 * np.linalg.norm(exact)
+
+
+@pytest.mark.parametrize("rec", [r for r in dc.geneo_refs() if r["geneo_lvl"].startswith("ASM")],
+                         ids=lambda r: r["file"][:-4])
+def test_dummy_goldens_on_gpu(lib, rec):
+    """The reference's own tst/dummy goldens (GenEO-1 / ASM rows) through the HIP library: local
+    matrices in, converged solution out (to PETSc print precision)."""
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC
+    d = dc.load()
+    mesh = decomp.read_input_text(d["inputs"][rec["input"] + ".inp"], rec["inpEps"])
+    ep, npart = dc.partition_for(rec)
+    dec = decomp.decompose(mesh, 2, ep, npart, rec["metis"] == "dual", rec["overlap"])
+    for p in range(2):
+        assert dc.same_rows(dc.rows_of(dec.domains[p].a_neu), rec["mats"][p])
+    a = decomp.global_matrix(mesh)
+    b = decomp.read_b_text(d["inputs"]["B.inp"], mesh.nbNode) if rec["use_b_file"] else decomp.rhs_default(a)
+    np.testing.assert_allclose(b, rec["b"], rtol=1e-6)
+    argv = ["-geneo_lvl", rec["geneo_lvl"], "-ksp_rtol", "1e-12", "-ksp_atol", "1e-12"]
+    if rec["geneo_cut"] > 0:
+        argv += ["-geneo_cut", str(rec["geneo_cut"])]
+    pc = GenEOPC(lib)
+    pc.set_from_options(argv)
+    assert ("INFO: %s pc" % pc.name) in rec["info"][2]
+    pc.set_sizes(mesh.nbNode, 2)
+    for dom in dec.domains:
+        pc.add_subdomain(dom.gid, dom.l2g, dom.mult, dom.a_neu, None)
+    pc.setup(b)
+    x, its, rnorm, reason = pc.solve(b)
+    assert reason.startswith("KSP_CONVERGED")
+    np.testing.assert_allclose(x, rec["x"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,108 @@
+"""-m gpu: every hand-written HIP kernel against numpy/scipy (FP64, tolerance 1e-12 relative unless
+stated), called through the C ABI of libgeneopc.so."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from geneo4petsc_amd import _lib
+    return _lib.load()          # raises if the HIP library is missing: no fallback
+
+
+def _rand_csr(n, density, seed, long_row=None):
+    rng = np.random.default_rng(seed)
+    a = sp.random(n, n, density=density, random_state=seed, format="csr")
+    a = a + sp.diags(rng.random(n) + 1.0)
+    if long_row is not None:
+        a = a.tolil()
+        a[long_row, :] = rng.random(n)
+        a = a.tocsr()
+    a.sort_indices()
+    return a
+
+
+def test_backend_is_hip(lib):
+    assert lib.GeneoBackendName() == b"hip-gfx950"
+
+
+def test_mfma_lane_map(lib):
+    assert lib.GeneoSelfTestMFMA() == 0
+
+
+@pytest.mark.parametrize("n,density,long_row", [(1, 1.0, None), (257, 0.02, None), (5000, 0.002, None),
+                                                (4000, 0.001, 17), (70000, 0.0001, None)])
+def test_spmv(lib, n, density, long_row):
+    from geneo4petsc_amd.pc import Spmv
+    a = _rand_csr(n, density, 1, long_row)
+    x = np.random.default_rng(2).random(n) - 0.5
+    y = Spmv(a, lib).apply(x)
+    np.testing.assert_allclose(y, a @ x, rtol=1e-13, atol=1e-13)
+
+
+def test_spmv_empty_rows(lib):
+    from geneo4petsc_amd.pc import Spmv
+    a = sp.csr_matrix(([1.0, 2.0], ([0, 3], [1, 2])), shape=(5, 5))
+    y = Spmv(a, lib).apply(np.arange(1.0, 6.0))
+    np.testing.assert_allclose(y, a @ np.arange(1.0, 6.0))
+
+
+def test_spmv_laplacian_7pt(lib):
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import Spmv
+    a = decomp.global_matrix(decomp.grid_mesh(n=40, dim=3))
+    x = np.random.default_rng(3).random(a.shape[0])
+    np.testing.assert_allclose(Spmv(a, lib).apply(x), a @ x, rtol=1e-13)
+
+
+@pytest.mark.parametrize("m", [1, 16, 20, 32, 64])
+def test_spmm(lib, m):
+    from geneo4petsc_amd.pc import Spmv
+    a = _rand_csr(3000, 0.003, 4)
+    rng = np.random.default_rng(5)
+    X = rng.random((3000, m)) - 0.5
+    pre, post = rng.random(3000) + 0.5, rng.random(3000) + 0.5
+    h = Spmv(a, lib)
+    np.testing.assert_allclose(h.spmm(X), a @ X, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(h.spmm(X, pre, post), post[:, None] * (a @ (pre[:, None] * X)), rtol=1e-12,
+                               atol=1e-13)
+
+
+@pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 48), (96, 96), (64, 32), (192, 192), (20, 12)])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_gram(lib, p, q, mfma):
+    from geneo4petsc_amd.pc import block_kernel
+    if not mfma and p * q > 256 * 40:
+        pytest.skip("FMA twin covers p*q <= 10240")
+    suboff = np.array([0, 1500, 1500 + 1024, 1500 + 1024 + 3333, 6000], dtype=np.int32)
+    rng = np.random.default_rng(6)
+    S, T = rng.random((6000, p)) - 0.5, rng.random((6000, q)) - 0.5
+    lib.GeneoSetMFMA(mfma)
+    try:
+        G, _ = block_kernel(0, suboff, S, T, lib)
+    finally:
+        lib.GeneoSetMFMA(1)
+    for s in range(4):
+        a, b = suboff[s], suboff[s + 1]
+        np.testing.assert_allclose(G[s], S[a:b].T @ T[a:b], rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 32), (96, 64), (64, 64), (192, 128), (96, 32), (20, 12)])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_block_mul(lib, p, q, mfma):
+    from geneo4petsc_amd.pc import block_kernel
+    suboff = np.array([0, 777, 777 + 2048, 5000], dtype=np.int32)
+    rng = np.random.default_rng(7)
+    S = rng.random((5000, p)) - 0.5
+    Cm = rng.random((3, p, q)) - 0.5          # asymmetric on purpose (catches row/col swaps)
+    lib.GeneoSetMFMA(mfma)
+    try:
+        Y, _ = block_kernel(1, suboff, S, Cm, lib)
+    finally:
+        lib.GeneoSetMFMA(1)
+    for s in range(3):
+        a, b = suboff[s], suboff[s + 1]
+        np.testing.assert_allclose(Y[a:b], S[a:b] @ Cm[s], rtol=1e-12, atol=1e-12)

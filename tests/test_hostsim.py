@@ -1,0 +1,94 @@
+"""Host logic of libgeneopc (core.cpp / capi.cpp: options, layout, LOBPCG driver, batched-CG driver,
+E assembly, apply modes, Krylov loops) exercised on CPU through the TEST-ONLY serial backend
+(tests/hostsim) and compared with the oracle.  The HIP kernels themselves are tested in -m gpu."""
+import numpy as np
+import pytest
+
+import cases
+import dummy_cases as dc
+import hostsim_util as hu
+
+TIGHT = ["-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return hu.hostsim_lib()
+
+
+@pytest.mark.parametrize("lvl,ksp,overlap", [("ASM,0", "cg", 1), ("ASM,1", "cg", 1), ("RAS,1", "gmres", 1),
+                                             ("SRAS,H1", "cg", 2), ("ASM,E1", "gmres", 1), ("ORAS,1", "gmres", 1)])
+def test_modes(lib, lvl, ksp, overlap):
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp, "-geneo_optim", "0.02"] + TIGHT
+    cases.compare_with_oracle(lib, 12, (2, 2, 2), overlap, argv)
+
+
+def test_dirichlet_built_from_matis(lib):
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "cg"] + TIGHT
+    cases.compare_with_oracle(lib, 10, (2, 2, 1), 1, argv, with_dir=False)
+
+
+def test_option_errors(lib):
+    from geneo4petsc_amd.pc import GenEOPC, GenEOError
+    pc = GenEOPC(lib)
+    assert pc.name == "geneo1ASM"                         # defaults, geneo.cpp:2649-2651
+    with pytest.raises(GenEOError, match="invalid option -geneo_lvl, unknown FOO"):
+        pc.set_from_options(["-geneo_lvl", "FOO,1"])
+    with pytest.raises(GenEOError, match="tau must be < 1"):
+        pc.set_from_options(["-geneo_tau", "1.5"])
+    pc2 = GenEOPC(lib)
+    pc2.set_from_options(["-geneo_lvl", "SORAS,H1", "-pc_type", "geneo", "-unknown_flag"])
+    assert pc2.name == "geneo1HSORAS"
+    pc3 = GenEOPC(lib)
+    pc3.set_from_options(["-geneo_lvl", "ASM,2"])
+    with pytest.raises(GenEOError):
+        pc3.set_sizes(4, 1)
+        pc3.setup()                                       # no subdomain / GenEO-2 not built: loud error
+
+
+@pytest.mark.parametrize("rec", [r for r in dc.geneo_refs() if r["geneo_lvl"].startswith("ASM")][::3],
+                         ids=lambda r: r["file"][:-4])
+def test_dummy_goldens(lib, rec):
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC
+    d = dc.load()
+    mesh = decomp.read_input_text(d["inputs"][rec["input"] + ".inp"], rec["inpEps"])
+    ep, npart = dc.partition_for(rec)
+    dec = decomp.decompose(mesh, 2, ep, npart, rec["metis"] == "dual", rec["overlap"])
+    a = decomp.global_matrix(mesh)
+    b = decomp.read_b_text(d["inputs"]["B.inp"], mesh.nbNode) if rec["use_b_file"] else decomp.rhs_default(a)
+    argv = ["-geneo_lvl", rec["geneo_lvl"], "-ksp_rtol", "1e-12", "-ksp_atol", "1e-12"]
+    if rec["geneo_cut"] > 0:
+        argv += ["-geneo_cut", str(rec["geneo_cut"])]
+    pc = GenEOPC(lib)
+    pc.set_from_options(argv)
+    assert ("INFO: %s pc" % pc.name) in rec["info"][2]
+    pc.set_sizes(mesh.nbNode, 2)
+    for dom in dec.domains:
+        pc.add_subdomain(dom.gid, dom.l2g, dom.mult, dom.a_neu, None)
+    pc.setup(b)
+    x, its, rnorm, reason = pc.solve(b)
+    assert reason.startswith("KSP_CONVERGED")
+    np.testing.assert_allclose(x, rec["x"], rtol=1e-5, atol=1e-6)
+
+
+def test_known_answer_E_and_Qb(lib):
+    """tridiag / dual: E = diag(10, 8), Qb = (2,2,2,4.25,6.5,6.5,6.5,6.5), nicolaides 2."""
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC
+    rec = [r for r in dc.geneo_refs() if r["file"] == "tridiag-pc=geneoASM1-metis=dual.ref"][0]
+    d = dc.load()
+    mesh = decomp.read_input_text(d["inputs"]["tridiag.inp"], 1.0)
+    ep, npart = dc.partition_for(rec)
+    dec = decomp.decompose(mesh, 2, ep, npart, True, 0)
+    b = decomp.rhs_default(decomp.global_matrix(mesh))
+    pc = GenEOPC(lib)
+    pc.set_from_options(["-geneo_lvl", "ASM,1"])
+    pc.set_sizes(8, 2)
+    for dom in dec.domains:
+        pc.add_subdomain(dom.gid, dom.l2g, dom.mult, dom.a_neu, None)
+    pc.setup(b)
+    info = pc.info()
+    assert info["nicolaidesLoc"] == 2 and info["dimE"] == 2 and list(pc.local_dims()) == [1, 1]
+    np.testing.assert_allclose(pc.E(), np.diag([10.0, 8.0]), atol=1e-12)
+    np.testing.assert_allclose(pc.apply_q(b), [2, 2, 2, 4.25, 6.5, 6.5, 6.5, 6.5], atol=1e-12)

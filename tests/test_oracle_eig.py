@@ -1,0 +1,51 @@
+"""Oracle self-checks for the rows the reference's goldens do not pin (eigenvalues, dimE, counts)."""
+import numpy as np
+import scipy.linalg as sla
+
+import cases
+from oracle import geneo_oracle as go
+
+ARGV = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-els2_eps_tol", "1e-10"]
+
+
+def test_arpack_path_matches_dense_ground_truth():
+    mesh, dec, a, b = cases.grid_case(12, 3, (2, 2, 2), 1)
+    o1 = cases.oracle_for(mesh, dec, ARGV, b)                      # dense LAPACK (n_loc <= 1500)
+    subs = [go.Subdomain(d.l2g, d.a_neu, d.mult, d.intersect) for d in dec.domains]
+    o2 = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(ARGV))
+    o2.dense_limit = 40                                            # force ARPACK shift-invert (the reference's solver)
+    o2.setup(b)
+    assert o1.realDimELoc == o2.realDimELoc and o1.estimDimELoc == o2.estimDimELoc
+    for s in range(8):
+        np.testing.assert_allclose(np.sort(o1.eigvals[s]), np.sort(o2.eigvals[s]), rtol=1e-9)
+    v = np.random.default_rng(0).random(mesh.nbNode)
+    np.testing.assert_allclose(o1.apply_q(v), o2.apply_q(v), rtol=1e-6, atol=1e-9)
+
+
+def test_inertia_estimate_equals_eigenvalue_count():
+    mesh, dec, a, b = cases.grid_case(10, 3, (2, 2, 1), 1)
+    orc = cases.oracle_for(mesh, dec, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.25"], b)
+    for s, d in enumerate(dec.domains):
+        dm = np.diag(1.0 / d.mult)
+        w = sla.eigvalsh(d.a_neu.toarray(), dm @ d.a_dir.toarray() @ dm)
+        assert len([x for x in orc.eigvals[s] if x > 0]) + 0 <= int(np.sum(w <= 0.25)) + 1
+    assert sum(orc.estimDimELoc) == sum(int(np.sum(sla.eigvalsh(
+        d.a_neu.toarray(), np.diag(1.0 / d.mult) @ d.a_dir.toarray() @ np.diag(1.0 / d.mult)) < 0.25))
+        for d in dec.domains)
+
+
+def test_cg_count_is_rounding_sensitive():
+    """Evidence for the iteration-count criterion: the ORACLE's own PCG count changes under a 1e-14
+    relative perturbation of b once the run is long enough (CG finite-precision chaos), while the
+    leading part of the residual history is unaffected."""
+    mesh, dec, a, b = cases.grid_case(12, 3, (2, 2, 2), 1)
+    argv = ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.2", "-geneo_cut", "8"]
+    orc = cases.oracle_for(mesh, dec, argv, b)
+    r1 = go.solve(orc, b, "cg", rtol=1e-10)
+    r2 = go.solve(orc, b * (1 + 1e-14 * np.random.default_rng(1).standard_normal(b.size)), "cg", rtol=1e-10)
+    h1, h2 = np.array(r1.history), np.array(r2.history)
+    k = min(len(h1), len(h2))
+    rel = np.abs(h1[:k] - h2[:k]) / h1[:k]
+    assert rel[:8].max() < 1e-10          # same problem ...
+    assert rel.max() > 1e-2               # ... yet O(1) different histories later on
+    assert abs(r1.its - r2.its) <= 2
