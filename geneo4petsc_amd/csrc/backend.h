@@ -42,6 +42,10 @@ struct Csr {
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 void csr_free(Csr& a);
 void spmv(const Csr& a, const double* x, double* y);                    // y = A x
+// In-situ timing of the SpMV launches issued between start and stop: every `every`-th launch is
+// bracketed by two HIP events on the backend stream (no host sync until stop).
+void spmv_profile_start(int every);
+void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post);

@@ -174,11 +174,58 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const int* __restrict__ rowblk
   }
 }
 
+struct SpmvProf {
+  bool on = false;
+  int every = 1;
+  long long nlaunch = 0;
+  std::vector<hipEvent_t> e0, e1;
+  std::vector<double> bytes;
+};
+static SpmvProf g_prof;
+void spmv_profile_start(int every) {
+  g_prof.on = true;
+  g_prof.every = every < 1 ? 1 : every;
+  g_prof.nlaunch = 0;
+  g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
+}
+void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
+  g_prof.on = false;
+  double ms = 0.0, by = 0.0;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  for (size_t i = 0; i < g_prof.e0.size(); ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, g_prof.e0[i], g_prof.e1[i]));
+    ms += t;
+    by += g_prof.bytes[i];
+    (void)hipEventDestroy(g_prof.e0[i]);
+    (void)hipEventDestroy(g_prof.e1[i]);
+  }
+  if (ms_sum) *ms_sum = ms;
+  if (bytes_sum) *bytes_sum = by;
+  if (nsampled) *nsampled = (long long)g_prof.e0.size();
+  if (nlaunch) *nlaunch = g_prof.nlaunch;
+  g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
+}
+
 void spmv(const Csr& a, const double* x, double* y) {
   if (a.n == 0) return;
   const int per = (a.nblk + 7) / 8;
+  const bool sample = g_prof.on && (g_prof.nlaunch++ % g_prof.every == 0) && g_prof.e0.size() < 20000;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (sample) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+  }
   hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
                      a.col, a.val, x, y);
+  if (sample) {
+    HIPCHK(hipEventRecord(e1, g_stream));
+    g_prof.e0.push_back(e0);
+    g_prof.e1.push_back(e1);
+    // algorithmic bytes: nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)
+    g_prof.bytes.push_back((double)a.nnz * 12.0 + ((double)a.n + 1.0) * 4.0 + (double)a.n * 16.0);
+  }
 }
 
 // =============================================================================== CSR SpMM

@@ -392,6 +392,16 @@ PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x, double* y, int reps, 
   GUARD_END((PC) nullptr)
   return 0;
 }
+PetscErrorCode GeneoSpmvProfileStart(int every) {
+  bk::spmv_profile_start(every);
+  return 0;
+}
+PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
+  GUARD_BEGIN
+  bk::spmv_profile_stop(ms_sum, bytes_sum, nsampled, nlaunch);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
 PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h) {
   if (!h || !*h) return 0;
   bk::csr_free((*h)->a);

@@ -105,12 +105,14 @@ def _kappa(interp, alpha, beta, x):
 
 
 def grid_mesh(size=4, weak=1, dim=3, inp_eps=1e-4, kappa_max=1.0, interp="", heat=False, lbd=1.0, dt=0.1,
-              n: Optional[int] = None) -> ElementMesh:
+              n: Optional[int] = None, window=None) -> ElementMesh:
     """tst/laplacian (laplacian.cpp:57-188) and tst/heat (heat.cpp:64-261) generators, vectorised.
 
     1-D edge elements kappa*[[1+eps,-1],[-1,1+eps]] (+ mass/dt for heat) created from the lower
     endpoint (whose coordinates give kappa = kappa(x) kappa(y) kappa(z)), plus one 1-node Dirichlet
     element kappa*(1+eps) per node of the face {last coordinate = 0}.  Element order = reference order.
+    ``window=(lo, hi)`` (3-tuples, hi exclusive) keeps only the elements whose nodes all lie in the
+    index box; node ids stay global (used by the windowed decomposition of large grids).
     """
     if n is None:
         n = grid_size(size, weak, dim)
@@ -123,9 +125,10 @@ def grid_mesh(size=4, weak=1, dim=3, inp_eps=1e-4, kappa_max=1.0, interp="", hea
         alpha = (kappa_max - beta) / xmax
     elif interp == "minmax":
         alpha, beta = kappa_max, xmax / 3.0
-    i = np.arange(d[0])[None, None, :]
-    j = np.arange(d[1])[None, :, None]
-    k = np.arange(d[2])[:, None, None]
+    lo, hi = ((0, 0, 0), tuple(d)) if window is None else window
+    i = np.arange(lo[0], hi[0])[None, None, :]
+    j = np.arange(lo[1], hi[1])[None, :, None]
+    k = np.arange(lo[2], hi[2])[:, None, None]
     cid = (i + d[0] * j + d[0] * d[1] * k)
     kap = (_kappa(interp, alpha, beta, i) * _kappa(interp, alpha, beta, j) * _kappa(interp, alpha, beta, k))
     kap = np.broadcast_to(kap, cid.shape)
@@ -134,7 +137,7 @@ def grid_mesh(size=4, weak=1, dim=3, inp_eps=1e-4, kappa_max=1.0, interp="", hea
     a_l, b_l, k_l, key_l, bc_l = [], [], [], [], []
     for ax in range(3):
         if d[ax] > 1:
-            m = coords[ax] < d[ax] - 1
+            m = coords[ax] < hi[ax] - 1
             c = cid[m]
             a_l.append(c); b_l.append(c + stride[ax]); k_l.append(kap[m])
             key_l.append(c * 6 + 2 * ax + 1); bc_l.append(np.zeros(c.size, dtype=bool))
@@ -402,3 +405,129 @@ def rank_plans(dec: Decomposition, owner_of_node: np.ndarray, sub_rank: np.ndarr
                               np.asarray(send_counts, dtype=np.int32),
                               np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32)))
     return plans
+
+
+# ------------------------------------------------------------------------------- large structured grids
+def grid_boxes(n, dim, parts_xyz):
+    """Index boxes (lo, hi exclusive) of structured_node_partition, in part-id order."""
+    px, py, pz = parts_xyz
+    d = [n if a < dim else 1 for a in range(3)]
+
+    def cuts(dd, p):
+        blk = (np.arange(dd) * p) // dd
+        return [(int(np.searchsorted(blk, b)), int(np.searchsorted(blk, b + 1))) for b in range(p)]
+
+    cx, cy, cz = cuts(d[0], px), cuts(d[1], py), cuts(d[2], pz)
+    boxes = []
+    for bk in range(pz):
+        for bj in range(py):
+            for bi in range(px):
+                boxes.append(((cx[bi][0], cy[bj][0], cz[bk][0]), (cx[bi][1], cy[bj][1], cz[bk][1])))
+    return boxes
+
+
+def _l1_dist_to_box(coords, lo, hi):
+    dist = 0
+    for c, a, b in zip(coords, lo, hi):
+        dist = dist + np.maximum(0, a - c) + np.maximum(0, c - (b - 1))
+    return dist
+
+
+def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, **gen) -> Domain:
+    """Domain p of a structured nodal decomposition WITHOUT touching the whole grid: everything that
+    determines domain p (its elements, the multiplicity of its nodes and elements, the assembled rows
+    of its nodes) lives inside box_p grown by 2*overlap+3 nodes, so the generic element-based
+    decomposition is run on that window only.  Identical output to decompose(...).domains[p]
+    (tests/test_decomp.py::test_windowed_equals_global)."""
+    d = [n if a < dim else 1 for a in range(3)]
+    boxes = grid_boxes(n, dim, parts_xyz)
+    lo, hi = boxes[p]
+    g = 2 * overlap + 3
+    wlo = tuple(max(0, lo[a] - g) if a < dim else 0 for a in range(3))
+    whi = tuple(min(d[a], hi[a] + g) if a < dim else 1 for a in range(3))
+    mesh = grid_mesh(n=n, dim=dim, window=(wlo, whi), **gen)
+    # window-local renumbering
+    wi = np.arange(wlo[0], whi[0])[None, None, :]
+    wj = np.arange(wlo[1], whi[1])[None, :, None]
+    wk = np.arange(wlo[2], whi[2])[:, None, None]
+    gids = (wi + d[0] * wj + d[0] * d[1] * wk).reshape(-1)          # ascending
+    nodes = mesh.nodes
+    loc = np.where(nodes >= 0, np.searchsorted(gids, np.where(nodes >= 0, nodes, gids[0])), -1)
+    wmesh = ElementMesh(gids.size, loc, mesh.mats)
+    shape = (whi[2] - wlo[2], whi[1] - wlo[1], whi[0] - wlo[0])
+    ci = np.broadcast_to(wi, shape).reshape(-1)
+    cj = np.broadcast_to(wj, shape).reshape(-1)
+    ck = np.broadcast_to(wk, shape).reshape(-1)
+    px, py, pz = parts_xyz
+    part = (ci * px) // d[0] + px * ((cj * py) // d[1] + py * ((ck * pz) // d[2]))
+    ids = np.unique(part)
+    remap = {int(q): t for t, q in enumerate(ids)}
+    npart = np.searchsorted(ids, part)
+    dec = decompose(wmesh, len(ids), None, npart, False, overlap, build=True, with_dirichlet=with_dirichlet,
+                    parts=[remap[p]])
+    dom = dec.domains[0]
+    dom.gid = p
+    dom.l2g = gids[dom.l2g]
+    inter = [np.zeros(0, dtype=np.int64) for _ in range(len(boxes))]
+    for q, t in remap.items():
+        inter[q] = dom.intersect[t]
+    dom.intersect = inter
+    return dom
+
+
+def grid_rank_plan(n, dim, parts_xyz, overlap, sub_rank, rank, size, my_domains) -> RankPlan:
+    """Ownership + halo lists of one rank for a structured nodal decomposition, computed locally.
+    A node belongs to domain s iff its L1 distance to box_s is <= overlap+1 (k layers of
+    element-sharing growth on the 1-D-edge grid graph; checked in tests against decompose())."""
+    d = [n if a < dim else 1 for a in range(3)]
+    boxes = grid_boxes(n, dim, parts_xyz)
+    px, py, pz = parts_xyz
+
+    def owner_of(gid):
+        i = gid % d[0]
+        j = (gid // d[0]) % d[1]
+        k = gid // (d[0] * d[1])
+        part = (i * px) // d[0] + px * ((j * py) // d[1] + py * ((k * pz) // d[2]))
+        return np.asarray(sub_rank)[part]
+
+    my_subs = [s for s in range(len(boxes)) if sub_rank[s] == rank]
+    owned = []
+    for s in my_subs:
+        lo, hi = boxes[s]
+        i = np.arange(lo[0], hi[0])[None, None, :]
+        j = np.arange(lo[1], hi[1])[None, :, None]
+        k = np.arange(lo[2], hi[2])[:, None, None]
+        owned.append((i + d[0] * j + d[0] * d[1] * k).reshape(-1))
+    owned = np.sort(np.concatenate(owned))
+    touched = np.unique(np.concatenate([dm.l2g for dm in my_domains]))
+    own_t = owner_of(touched)
+    halo = touched[own_t != rank]
+    order = np.lexsort((halo, owner_of(halo)))
+    halo = halo[order]
+    recv_counts = np.bincount(owner_of(halo), minlength=size).astype(np.int32)
+    # what every other rank needs from me
+    send = [[] for _ in range(size)]
+    r1 = overlap + 1
+    for s, (slo, shi) in enumerate(boxes):
+        q = int(sub_rank[s])
+        if q == rank:
+            continue
+        for t in my_subs:
+            tlo, thi = boxes[t]
+            lo = [max(tlo[a], slo[a] - r1) for a in range(3)]
+            hi = [min(thi[a], shi[a] + r1) for a in range(3)]
+            if any(lo[a] >= hi[a] for a in range(3)):
+                continue
+            i = np.arange(lo[0], hi[0])[None, None, :]
+            j = np.arange(lo[1], hi[1])[None, :, None]
+            k = np.arange(lo[2], hi[2])[:, None, None]
+            dist = _l1_dist_to_box((i, j, k), slo, shi)
+            gid = np.broadcast_to(i + d[0] * j + d[0] * d[1] * k, dist.shape)
+            send[q].append(gid[dist <= r1])
+    send_idx, send_counts = [], []
+    for q in range(size):
+        g = np.unique(np.concatenate(send[q])) if send[q] else np.zeros(0, dtype=np.int64)
+        send_idx.append(np.searchsorted(owned, g))
+        send_counts.append(g.size)
+    return RankPlan(rank, size, my_subs, owned, halo, recv_counts, np.asarray(send_counts, dtype=np.int32),
+                    np.concatenate(send_idx).astype(np.int32))

@@ -159,6 +159,10 @@ PetscErrorCode GeneoSpmvApply(GeneoSpmv h, const double* x_dev, double* y_dev);
 /* average kernel time of `reps` back-to-back launches, HIP events on the library stream */
 PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x_dev, double* y_dev, int reps, double* ms_avg);
 PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h);
+/* in-situ timing of every `every`-th CSR SpMV launch the library issues (solve loops included):
+ * HIP events on the launch stream; stop returns the summed kernel ms and algorithmic bytes. */
+PetscErrorCode GeneoSpmvProfileStart(int every);
+PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
 /* Y = post.*(A (pre.*X)), row-major n x m blocks */
 PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, int m, const double* pre_dev,
                               const double* post_dev);

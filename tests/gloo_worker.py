@@ -1,0 +1,65 @@
+"""Worker of tests/test_gloo.py: world_size ranks over gloo, each holding half of the subdomains,
+running the multi-rank path of libgeneopc's host logic (test-only hostsim backend: "device"
+pointers are host pointers, so the torch CPU staging buffers can be handed over directly)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out_path, lvl, ksp = sys.argv[1], sys.argv[2], sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    import hostsim_util as hu
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.comm import TorchComm, gather_owned
+    from geneo4petsc_amd.pc import GenEOPC
+    n, parts, ov = 12, (2, 2, 2), 1
+    nb = 8
+    sub_rank = np.arange(nb) * size // nb
+    doms = [decomp.decompose_grid_domain(n, 3, parts, ov, s) for s in range(nb) if sub_rank[s] == rank]
+    plan = decomp.grid_rank_plan(n, 3, parts, ov, sub_rank, rank, size, doms)
+    lib = hu.hostsim_lib()
+    comm = TorchComm(plan, "cpu")
+    pc = GenEOPC(lib)
+    pc.set_from_options(["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp,
+                         "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"])
+    pc.set_sizes(n ** 3, nb)
+    comm.attach(pc)
+    for d in doms:
+        pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+    # b = A (1..N) on the owned rows, from the Dirichlet rows of the domain that owns each node
+    xstar = np.arange(1.0, n ** 3 + 1.0)
+    b = np.zeros(len(plan.owned))
+    boxes = decomp.grid_boxes(n, 3, parts)
+    for d in doms:
+        rows = d.a_dir @ xstar[d.l2g]
+        sel = np.isin(d.l2g, plan.owned) & (decomp.structured_node_partition(n, 3, parts)[d.l2g] == d.gid)
+        b[np.searchsorted(plan.owned, d.l2g[sel])] = rows[sel]
+    pc.setup(b)
+    x, its, rnorm, reason = pc.solve(b)
+    y = pc.apply(b)
+    m = pc.matmult(b)
+    res = dict(its=its, reason=reason, dims=[int(v) for v in pc.local_dims()], dimE=pc.info()["dimE"])
+    xf = gather_owned(x, plan, n ** 3)
+    yf = gather_owned(y, plan, n ** 3)
+    mf = gather_owned(m, plan, n ** 3)
+    bf = gather_owned(b, plan, n ** 3)
+    if rank == 0:
+        np.savez(out_path, x=xf, y=yf, m=mf, b=bf, meta=json.dumps(res))
+    if comm.error is not None:
+        raise comm.error
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""N > 1 path on CPU: world_size 2 over gloo.  Each rank holds 4 of the 8 subdomains; halo exchange
+and all-reduces go through geneo4petsc_amd.comm.TorchComm; the result must equal the serial oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import geneo_oracle as go
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("lvl,ksp", [("ASM,1", "cg"), ("RAS,H1", "gmres")])
+def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp):
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "gloo_worker.py"),
+           out, lvl, ksp]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    meta = json.loads(str(got["meta"]))
+    mesh, dec, a, b = cases.grid_case(12, 3, (2, 2, 2), 1)
+    np.testing.assert_allclose(got["b"], b, rtol=1e-13)
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp, "-els2_eps_tol", "1e-10",
+            "-ksp_rtol", "1e-8"]
+    orc = cases.oracle_for(mesh, dec, argv, b)
+    kspname, kw = cases.ksp_args(argv)
+    res = go.solve(orc, b, kspname, **kw)
+    assert meta["dims"] == orc.realDimELoc and meta["dimE"] == orc.dimE
+    assert meta["reason"] == res.reason
+    assert abs(meta["its"] - res.its) <= (2 if ksp == "cg" else 0)
+    np.testing.assert_allclose(got["m"], orc.matmult(b), rtol=1e-12, atol=1e-9)
+    assert np.linalg.norm(got["y"] - orc.apply(b)) <= 1e-9 * np.linalg.norm(orc.apply(b))
+    assert np.linalg.norm(got["x"] - res.x) <= 1e-7 * np.linalg.norm(res.x)
