@@ -239,7 +239,7 @@ def main():
             "local_solve_cg_iterations": info["dls1_iterations"], "host_prep_s": prep_s,
             "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs_rank / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_spmv_lds", "launches_timed": int(nsamp.value),
+                         "kernel": lib.GeneoSpmvKernelName().decode(), "launches_timed": int(nsamp.value),
                          "launches_total": int(nlaunch.value),
                          "avg_launch_ms": ms_sum.value / max(1, nsamp.value),
                          "algorithmic_bytes_per_launch": by_sum.value / max(1, nsamp.value)},

@@ -81,6 +81,8 @@ SYMBOLS = {
     "GeneoDeviceSync": (C.c_int, []),
     "GeneoSelfTestMFMA": (C.c_int, []),
     "GeneoSetMFMA": (C.c_int, [C.c_int]),
+    "GeneoSetSpmvKind": (C.c_int, [C.c_int]),
+    "GeneoSpmvKernelName": (C.c_char_p, []),
     "GeneoSpmvCreate": (C.c_int, [C.POINTER(GeneoCsr), C.POINTER(C.c_void_p)]),
     "GeneoSpmvApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "GeneoSpmvTime": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),

@@ -38,6 +38,16 @@ struct Csr {
   int* rowblk = nullptr;  // nblk+1 : first row of each LDS row block
   int nblk = 0;
   int max_row = 0;
+  // CSR tiles re-laid out for the wave: 64-row slices, entries k-major inside a slice
+  // (element (row i, k-th nonzero) at sl_ptr[s] + 64*k + i, zero-padded to the slice's longest
+  // short row); rows longer than SELL_LONG stay in CSR and go through the long-row kernel.
+  int64_t* sl_ptr = nullptr;   // nslice+1
+  int* sl_col = nullptr;
+  double* sl_val = nullptr;
+  int nslice = 0;
+  int* long_rows = nullptr;    // rows handled by the long-row kernel
+  int nlong = 0;
+  int64_t sl_nnz = 0;          // stored entries incl. padding
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 void csr_free(Csr& a);
@@ -107,6 +117,9 @@ void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double 
 // Y = a * d .* X + b * Y  (row scaling by d[i])
 void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,
                     int m);
+// fused Chebyshev step on contiguous n x m blocks (z strided): r -= ad ; d = a*dinv.*r + b*d ; z += d
+void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
+                 int n, int m);
 void block_colscale(const Chunks& c, double* X, int ldx, int m, const double* colscale);  // X[:,j]*=cs[s*m+j]
 // deterministic counter-based start block; column 0 is the constant vector
 void block_init(const Chunks& c, double* X, int ldx, int m, const int* sub_gid, uint64_t seed);
@@ -124,6 +137,8 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
              const double* yE, double* wL, bool accumulate);
 
 // ---- misc -------------------------------------------------------------------------------------
+void  set_spmv_kind(int kind);  // 0: LDS row-block kernel, 1: 64-row sliced kernel (default)
+const char* spmv_kernel_name();
 void  set_mfma(bool enable);   // false: run the plain-FMA twins of the MFMA kernels (validation)
 int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as the kernels assume
 void* event_create();

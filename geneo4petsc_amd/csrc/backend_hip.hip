@@ -83,9 +83,23 @@ static inline int grid1d(int64_t n, int per_block) {
   return g < 1 ? 1 : g;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum_256(double v, double* sm /*>=4*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];  // every thread gets the same, fixed-order value
+}
 // =============================================================================== CSR SpMV
 constexpr int SPMV_TILE = 1792;  // nnz staged in LDS per workgroup (14 KB): 256 rows x 7 nnz
 constexpr int SPMV_ROWS = 256;   // rows per row block (one row per thread in the reduce phase)
+constexpr int SELL_LONG = 64;    // rows longer than this bypass the sliced layout
 
 Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
@@ -121,10 +135,57 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   a.nblk = (int)blk.size() - 1;
   a.rowblk = (int*)alloc(sizeof(int) * blk.size());
   h2d(a.rowblk, blk.data(), sizeof(int) * blk.size());
+  // 64-row slices, k-major, padded per slice (long rows excluded)
+  {
+    const int ns = (n + 63) / 64;
+    std::vector<int64_t> sp(ns + 1, 0);
+    std::vector<int> longr;
+    for (int s = 0; s < ns; ++s) {
+      int w = 0;
+      for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
+        const int len = h_rowptr[i + 1] - h_rowptr[i];
+        if (len > SELL_LONG) longr.push_back(i);
+        else w = std::max(w, len);
+      }
+      sp[s + 1] = sp[s] + (int64_t)64 * w;
+    }
+    std::vector<int> sc((size_t)std::max<int64_t>(1, sp[ns]), 0);
+    std::vector<double> sv((size_t)std::max<int64_t>(1, sp[ns]), 0.0);
+    for (int s = 0; s < ns; ++s) {
+      const int w = (int)((sp[s + 1] - sp[s]) / 64);
+      for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
+        const int len = h_rowptr[i + 1] - h_rowptr[i];
+        const int li = i - 64 * s;
+        const bool is_long = len > SELL_LONG;
+        for (int k = 0; k < w; ++k) {
+          const int64_t e = sp[s] + (int64_t)64 * k + li;
+          if (!is_long && k < len) {
+            sc[e] = h_col[h_rowptr[i] + k];
+            sv[e] = h_val[h_rowptr[i] + k];
+          } else {
+            sc[e] = h_col[h_rowptr[i]] * 0 + (len > 0 ? h_col[h_rowptr[i]] : 0);  // any valid column
+            sv[e] = 0.0;
+          }
+        }
+      }
+    }
+    a.nslice = ns;
+    a.sl_nnz = sp[ns];
+    a.sl_ptr = (int64_t*)alloc(sizeof(int64_t) * (ns + 1));
+    a.sl_col = (int*)alloc(sizeof(int) * sc.size());
+    a.sl_val = (double*)alloc(sizeof(double) * sv.size());
+    h2d(a.sl_ptr, sp.data(), sizeof(int64_t) * (ns + 1));
+    h2d(a.sl_col, sc.data(), sizeof(int) * sc.size());
+    h2d(a.sl_val, sv.data(), sizeof(double) * sv.size());
+    a.nlong = (int)longr.size();
+    a.long_rows = (int*)alloc(sizeof(int) * std::max<size_t>(1, longr.size()));
+    h2d(a.long_rows, longr.data(), sizeof(int) * longr.size());
+  }
   return a;
 }
 void csr_free(Csr& a) {
   dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
+  dfree(a.sl_ptr); dfree(a.sl_col); dfree(a.sl_val); dfree(a.long_rows);
   a = Csr();
 }
 
@@ -174,6 +235,53 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const int* __restrict__ rowblk
   }
 }
 
+// Sliced kernel: one wave per 64-row slice, lane i owns row i.  Per k the wave issues one coalesced
+// 512-B val load, one 256-B col load and one x gather whose 64 addresses are the k-th neighbours of
+// 64 consecutive rows (contiguous for stencil-like matrices) -- no LDS round trip, no barrier.
+__global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ sl_ptr, int nslice, int n,
+                                                   const int* __restrict__ col, const double* __restrict__ val,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  const int nwb = (nslice + 3) >> 2;            // workgroups (4 slices each)
+  const int t = xcd_remap(blockIdx.x, nwb);
+  const int s = 4 * t + (threadIdx.x >> 6);
+  if (t >= nwb || s >= nslice) return;
+  const int l = threadIdx.x & 63;
+  const int64_t a = sl_ptr[s], b = sl_ptr[s + 1];
+  double acc0 = 0.0, acc1 = 0.0;
+  int64_t e = a + l;
+  for (; e + 64 < b; e += 128) {
+    const int c0 = col[e], c1 = col[e + 64];
+    const double v0 = val[e], v1 = val[e + 64];
+    acc0 += v0 * x[c0];
+    acc1 += v1 * x[c1];
+  }
+  if (e < b) acc0 += val[e] * x[col[e]];
+  const int r = 64 * s + l;
+  if (r < n) y[r] = acc0 + acc1;
+}
+// rows excluded from the slices (longer than SELL_LONG): one workgroup per row
+__global__ __launch_bounds__(256) void k_spmv_long(const int* __restrict__ rows, const int* __restrict__ rowptr,
+                                                   const int* __restrict__ col, const double* __restrict__ val,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double sm[4];
+  const int r = rows[blockIdx.x];
+  double s = 0.0;
+  for (int k = rowptr[r] + threadIdx.x; k < rowptr[r + 1]; k += 256) s += val[k] * x[col[k]];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) y[r] = s;
+}
+
+static int g_spmv_kind = -1;  // 0 = LDS row blocks, 1 = 64-row slices
+static int spmv_kind() {
+  if (g_spmv_kind < 0) {
+    const char* e = getenv("GENEO_SPMV");
+    g_spmv_kind = (e && std::string(e) == "lds") ? 0 : 1;
+  }
+  return g_spmv_kind;
+}
+const char* spmv_kernel_name() { return spmv_kind() == 0 ? "k_spmv_lds" : "k_spmv_sell"; }
+void set_spmv_kind(int kind) { g_spmv_kind = kind ? 1 : 0; }
+
 struct SpmvProf {
   bool on = false;
   int every = 1;
@@ -217,8 +325,18 @@ void spmv(const Csr& a, const double* x, double* y) {
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
   }
-  hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
-                     a.col, a.val, x, y);
+  if (spmv_kind() == 0) {
+    hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
+                       a.col, a.val, x, y);
+  } else {
+    const int nwb = (a.nslice + 3) / 4;
+    const int perw = (nwb + 7) / 8;
+    hipLaunchKernelGGL(k_spmv_sell, dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, a.sl_col,
+                       a.sl_val, x, y);
+    if (a.nlong > 0)
+      hipLaunchKernelGGL(k_spmv_long, dim3(a.nlong), dim3(256), 0, g_stream, a.long_rows, a.rowptr, a.col, a.val,
+                         x, y);
+  }
   if (sample) {
     HIPCHK(hipEventRecord(e1, g_stream));
     g_prof.e0.push_back(e0);
@@ -229,7 +347,9 @@ void spmv(const Csr& a, const double* x, double* y) {
 }
 
 // =============================================================================== CSR SpMM
-// LPR lanes cooperate on one row, each lane owns columns j = lane, lane+LPR, ...
+// LPR lanes cooperate on one row.  The row's (col,val) pairs are fetched LPR at a time with ONE
+// coalesced load per lane group and broadcast with shuffles, so the X-row loads of a chunk carry no
+// dependent global load in front of them and overlap; lane j owns output columns j, j+LPR, ...
 template <int LPR>
 __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ rowptr,
                                               const int* __restrict__ col, const double* __restrict__ val,
@@ -239,18 +359,43 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
   constexpr int RPB = 256 / LPR;
   const int lane = threadIdx.x % LPR;
   const int rloc = threadIdx.x / LPR;
-  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
-    const int a = rowptr[r], b = rowptr[r + 1];
-    for (int j = lane; j < m; j += LPR) {
-      double s = 0.0;
-      for (int k = a; k < b; ++k) {
-        const int c = col[k];
-        double v = val[k];
-        if (pre) v *= pre[c];
-        s += v * X[(int64_t)c * ldx + j];
+  const int nrounds = (n + gridDim.x * RPB - 1) / (gridDim.x * RPB);
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int64_t r = ((int64_t)rd * gridDim.x + blockIdx.x) * RPB + rloc;
+    const bool live = r < n;   // keep every lane in the shuffles
+    const int a = live ? rowptr[r] : 0, b = live ? rowptr[r + 1] : 0;
+    for (int j0 = 0; j0 < m; j0 += LPR) {
+      const int j = j0 + lane;
+      double s0 = 0.0, s1 = 0.0;
+      for (int base = a; base < b; base += LPR) {
+        int myc = 0;
+        double myv = 0.0;
+        if (base + lane < b) {
+          myc = col[base + lane];
+          myv = val[base + lane];
+          if (pre) myv *= pre[myc];
+        }
+        const int cnt = (b - base < LPR) ? b - base : LPR;
+        int k = 0;
+        for (; k + 1 < cnt; k += 2) {
+          const int c0 = __shfl(myc, k, LPR), c1 = __shfl(myc, k + 1, LPR);
+          const double v0 = __shfl(myv, k, LPR), v1 = __shfl(myv, k + 1, LPR);
+          if (j < m) {
+            s0 += v0 * X[(int64_t)c0 * ldx + j];
+            s1 += v1 * X[(int64_t)c1 * ldx + j];
+          }
+        }
+        if (k < cnt) {
+          const int c0 = __shfl(myc, k, LPR);
+          const double v0 = __shfl(myv, k, LPR);
+          if (j < m) s0 += v0 * X[(int64_t)c0 * ldx + j];
+        }
       }
-      if (post) s *= post[r];
-      Y[r * ldy + j] = s;
+      if (live && j < m) {
+        double sacc = s0 + s1;
+        if (post) sacc *= post[r];
+        Y[r * ldy + j] = sacc;
+      }
     }
   }
 }
@@ -370,19 +515,6 @@ constexpr int DOT_BLOCKS = 1024;
 static double* g_dot_work = nullptr;
 int dot_work_doubles() { return DOT_BLOCKS; }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double block_sum_256(double v, double* sm /*>=4*/) {
-  v = wave_sum(v);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  __syncthreads();
-  if (l == 0) sm[w] = v;
-  __syncthreads();
-  return sm[0] + sm[1] + sm[2] + sm[3];  // every thread gets the same, fixed-order value
-}
 __global__ __launch_bounds__(256) void k_dot1(const double* __restrict__ x, const double* __restrict__ y,
                                               int64_t n, double* __restrict__ part) {
   __shared__ double sm[4];
@@ -449,6 +581,15 @@ __device__ __forceinline__ double sub_total(const double* __restrict__ part, int
   double s = 0.0;
   for (int c = c0; c < c1; ++c) s += part[(int64_t)slot * nchunk + c];
   return s;
+}
+
+// the same total computed cooperatively by the 256 threads of a workgroup (strided partial sums in a
+// fixed pattern + the fixed-order block reduction => bitwise identical in every workgroup)
+__device__ __forceinline__ double sub_total_block(const double* __restrict__ part, int nchunk, int slot, int c0,
+                                                  int c1, double* sm) {
+  double s = 0.0;
+  for (int c = c0 + (int)threadIdx.x; c < c1; c += 256) s += part[(int64_t)slot * nchunk + c];
+  return block_sum_256(s, sm);
 }
 
 __global__ __launch_bounds__(256) void k_seg_dot1(const int* __restrict__ start, const int* __restrict__ len,
@@ -539,7 +680,7 @@ __global__ __launch_bounds__(256) void k_cg_update(const int* __restrict__ start
   const int c = blockIdx.x;
   const int s = sub[c];
   const int c0 = subptr[s], c1 = subptr[s + 1];
-  const double pap = sub_total(part, nchunk, 0, c0, c1);
+  const double pap = sub_total_block(part, nchunk, 0, c0, c1, sm);
   const double rz = sc[(int64_t)s * 8 + parity];
   const double active = sc[(int64_t)s * 8 + 6];
   const double alpha = (active != 0.0 && pap != 0.0) ? rz / pap : 0.0;
@@ -577,11 +718,12 @@ __global__ __launch_bounds__(256) void k_cg_direction(const int* __restrict__ st
                                                       double* __restrict__ sc, int parity, double* __restrict__ p,
                                                       const double* __restrict__ z, double tol2,
                                                       const double* __restrict__ part, int nchunk) {
+  __shared__ double sm[4];
   const int c = blockIdx.x;
   const int s = sub[c];
   const int c0 = subptr[s], c1 = subptr[s + 1];
-  const double nrz = sub_total(part, nchunk, 1, c0, c1);
-  const double nrr = sub_total(part, nchunk, 2, c0, c1);
+  const double nrz = sub_total_block(part, nchunk, 1, c0, c1, sm);
+  const double nrr = sub_total_block(part, nchunk, 2, c0, c1, sm);
   const double rz = sc[(int64_t)s * 8 + parity];
   const double was_active = sc[(int64_t)s * 8 + 6];
   const double rr0 = sc[(int64_t)s * 8 + 7];
@@ -615,7 +757,7 @@ void cg_direction(const Chunks& c, double* sc, int parity, double* p, const doub
 
 // =============================================================================== tall-skinny blocks
 // Gram row ranges: GRAM_CH consecutive chunks of one subdomain per workgroup.
-constexpr int GRAM_CH = 4;
+constexpr int GRAM_CH = 1;
 
 using d4 = __attribute__((ext_vector_type(4))) double;
 
@@ -623,14 +765,18 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 //   A operand lane l: A[i = l&15][k = l>>4]   -> S[row0 + 4*step + (l>>4)][16*I + (l&15)]
 //   B operand lane l: B[k = l>>4][j = l&15]   -> T[row0 + 4*step + (l>>4)][16*J + (l&15)]
 //   C/D lane l, reg v: row i = (l>>4) + 4*v, col j = l&15         (cdna_hip_programming.md s3)
-// 4 waves; wave w owns output tiles t = w, w+4, ... (t = I*Q16 + J), at most TPW tiles.
-template <int TPW>
+// The 4 waves form a 2 x 2 grid; wave (wi, wj) owns the TI x TJ block of 16x16 output tiles
+// I = I0 + wi*TI + a, J = J0 + wj*TJ + b, so each 4-row step costs TI + TJ LDS fragment reads for
+// TI*TJ MFMAs.  16-row slabs of S and T go HBM -> registers -> LDS; the next slab's loads are issued
+// before the MFMA phase of the current one (register double buffering).
+template <int TI, int TJ>
 __global__ __launch_bounds__(256) void k_gram_mfma(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                    const int* __restrict__ gfirst, const int* __restrict__ gcount,
                                                    const double* __restrict__ S, int lds_, int p,
                                                    const double* __restrict__ T, int ldt_, int q,
-                                                   double* __restrict__ Gpart, int tile0) {
+                                                   double* __restrict__ Gpart, int I0, int J0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NC = 3;                          // p, q <= 192
   const int ldS = (p % 32 == 0) ? p + 16 : p;  // rows r, r+1 land 32 banks apart
   const int ldT = (q % 32 == 0) ? q + 16 : q;
   double* sS = smem;             // 16 x ldS
@@ -641,47 +787,82 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const int* __restrict__ cstar
   int nrows = 0;
   for (int c = 0; c < nc; ++c) nrows += clen[c0 + c];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  const int P16 = p >> 4, Q16 = q >> 4, NT = P16 * Q16;
-  d4 acc[TPW];
+  const int P16 = p >> 4, Q16 = q >> 4;
+  const int wi = w >> 1, wj = w & 1;
+  int aoff[TI], boff[TJ];
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int a = 0; a < TI; ++a) {
+    int I = I0 + wi * TI + a;
+    if (I >= P16) I = P16 - 1;
+    aoff[a] = 16 * I + (l & 15);
+  }
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) {
+    int J = J0 + wj * TJ + b;
+    if (J >= Q16) J = Q16 - 1;
+    boff[b] = 16 * J + (l & 15);
+  }
+  d4 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  double rs[4][NC], rt[4][NC];
+  auto load_slab = [&](int r) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 4 * w + u;
+      const bool ok = rr < nrows;
+      const double* srow = S + (int64_t)(row0 + (ok ? rr : 0)) * lds_;
+      const double* trow = T + (int64_t)(row0 + (ok ? rr : 0)) * ldt_;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        const int cc = l + 64 * ci;
+        rs[u][ci] = (ok && cc < p) ? srow[cc] : 0.0;
+        rt[u][ci] = (ok && cc < q) ? trow[cc] : 0.0;
+      }
+    }
+  };
+  load_slab(0);
   for (int r = 0; r < nrows; r += 16) {
-    const int nr = (nrows - r < 16) ? nrows - r : 16;
+    __syncthreads();  // every wave is done reading the previous slab
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        const int cc = l + 64 * ci;
+        if (cc < p) sS[(4 * w + u) * ldS + cc] = rs[u][ci];
+        if (cc < q) sT[(4 * w + u) * ldT + cc] = rt[u][ci];
+      }
     __syncthreads();
-    for (int e = tid; e < 16 * p; e += 256) {
-      const int rr = e / p, cc = e - rr * p;
-      sS[rr * ldS + cc] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
-    }
-    for (int e = tid; e < 16 * q; e += 256) {
-      const int rr = e / q, cc = e - rr * q;
-      sT[rr * ldT + cc] = (rr < nr) ? T[(int64_t)(row0 + r + rr) * ldt_ + cc] : 0.0;
-    }
-    __syncthreads();
+    if (r + 16 < nrows) load_slab(r + 16);  // in flight during the MFMA phase
 #pragma unroll
     for (int step = 0; step < 4; ++step) {
       const int kr = 4 * step + (l >> 4);
+      double av[TI], bv[TJ];
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int t = tile0 + w + 4 * i;
-        if (t < NT) {
-          const int I = t / Q16, J = t - I * Q16;
-          const double a = sS[kr * ldS + 16 * I + (l & 15)];
-          const double b = sT[kr * ldT + 16 * J + (l & 15)];
-          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
-        }
-      }
+      for (int a = 0; a < TI; ++a) av[a] = sS[kr * ldS + aoff[a]];
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) bv[b] = sT[kr * ldT + boff[b]];
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
   }
   double* G = Gpart + (int64_t)g * p * q;
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = tile0 + w + 4 * i;
-    if (t < NT) {
-      const int I = t / Q16, J = t - I * Q16;
+  for (int a = 0; a < TI; ++a) {
+    const int I = I0 + wi * TI + a;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 16 * I + (l >> 4) + 4 * v, colj = 16 * J + (l & 15);
-        G[(int64_t)row * q + colj] = acc[i][v];
+    for (int b = 0; b < TJ; ++b) {
+      const int J = J0 + wj * TJ + b;
+      if (I < P16 && J < Q16) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = 16 * I + (l >> 4) + 4 * v, colj = 16 * J + (l & 15);
+          G[(int64_t)row * q + colj] = acc[a][b][v];
+        }
       }
     }
   }
@@ -807,12 +988,26 @@ void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, in
   if (mfma_ok) {
     const int ldS = (p % 32 == 0) ? p + 16 : p, ldT = (q % 32 == 0) ? q + 16 : q;
     const size_t sm = sizeof(double) * 16 * (size_t)(ldS + ldT);
-    const int NT = (p / 16) * (q / 16);
-    constexpr int TPW = 9;  // 36 tiles per launch (p = q = 96)
-    for (int tile0 = 0; tile0 < NT; tile0 += 4 * TPW) {
-      hipLaunchKernelGGL(k_gram_mfma<TPW>, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst,
-                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, tile0);
-    }
+    const int P16 = p / 16, Q16 = q / 16;
+    const int ti = std::min(3, (P16 + 1) / 2), tj = std::min(3, (Q16 + 1) / 2);
+    for (int I0 = 0; I0 < P16; I0 += 2 * ti)
+      for (int J0 = 0; J0 < Q16; J0 += 2 * tj) {
+#define GRAM_LAUNCH(A, B)                                                                                       \
+  hipLaunchKernelGGL((k_gram_mfma<A, B>), dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, \
+                     pl.gcount, S, lds_, p, T, ldt_, q, pl.part, I0, J0)
+        switch (ti * 10 + tj) {
+          case 11: GRAM_LAUNCH(1, 1); break;
+          case 12: GRAM_LAUNCH(1, 2); break;
+          case 13: GRAM_LAUNCH(1, 3); break;
+          case 21: GRAM_LAUNCH(2, 1); break;
+          case 22: GRAM_LAUNCH(2, 2); break;
+          case 23: GRAM_LAUNCH(2, 3); break;
+          case 31: GRAM_LAUNCH(3, 1); break;
+          case 32: GRAM_LAUNCH(3, 2); break;
+          default: GRAM_LAUNCH(3, 3); break;
+        }
+#undef GRAM_LAUNCH
+      }
   } else {
     if ((size_t)p * q > 256 * 40) throw std::runtime_error("gram: p*q too large for the FMA kernel");
     const size_t sm = sizeof(double) * 16 * (size_t)(p + q);
@@ -838,7 +1033,9 @@ __global__ __launch_bounds__(256) void k_blockmul_mfma(const int* __restrict__ c
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int p = 4 * P4;
   constexpr int ldS = p + ((34 - (p % 32)) % 32);  // = 2 (mod 32)
-  double* sS = smem;                               // 64 x ldS
+  constexpr int NC = (p + 63) / 64;
+  constexpr int SR = 32;                           // slab rows (2 row tiles)
+  double* sS = smem;                               // SR x ldS
   const int c = blockIdx.x;
   const int row0 = cstart[c], nrows = clen[c], s = csub[c];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -847,20 +1044,39 @@ __global__ __launch_bounds__(256) void k_blockmul_mfma(const int* __restrict__ c
   const int nJ = Q16 < 4 ? Q16 : 4;  // Q16 in {1,2,4,8,...}
   const int rtw = 4 / nJ;            // waves sharing one column tile
   const int jsel = w % nJ, rsel = w / nJ;
+  double rg[SR / 4][NC];             // wave w stages slab rows 8w..8w+7
+  auto load_slab = [&](int r) {
+#pragma unroll
+    for (int u = 0; u < SR / 4; ++u) {
+      const int rr = r + (SR / 4) * w + u;
+      const bool ok = rr < nrows;
+      const double* srow = S + (int64_t)(row0 + (ok ? rr : 0)) * lds_;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        const int cc = l + 64 * ci;
+        rg[u][ci] = (ok && cc < p) ? srow[cc] : 0.0;
+      }
+    }
+  };
   for (int Jbase = 0; Jbase < Q16; Jbase += nJ) {
     const int J = Jbase + jsel;
     double bfrag[P4];
 #pragma unroll
     for (int kk = 0; kk < P4; ++kk) bfrag[kk] = Cs[(int64_t)(4 * kk + (l >> 4)) * q + 16 * J + (l & 15)];
-    for (int r = 0; r < nrows; r += 64) {
-      const int nr = (nrows - r < 64) ? nrows - r : 64;
+    load_slab(0);
+    for (int r = 0; r < nrows; r += SR) {
+      const int nr = (nrows - r < SR) ? nrows - r : SR;
       __syncthreads();
-      for (int e = tid; e < 64 * p; e += 256) {
-        const int rr = e / p, cc = e - rr * p;
-        sS[rr * ldS + cc] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
-      }
+#pragma unroll
+      for (int u = 0; u < SR / 4; ++u)
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          const int cc = l + 64 * ci;
+          if (cc < p) sS[((SR / 4) * w + u) * ldS + cc] = rg[u][ci];
+        }
       __syncthreads();
-      for (int rt = rsel; rt < 4; rt += rtw) {
+      if (r + SR < nrows) load_slab(r + SR);  // next slab in flight during the MFMA phase
+      for (int rt = rsel; rt < SR / 16; rt += rtw) {
         if (16 * rt >= nr) break;
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         if (accumulate) {
@@ -903,7 +1119,7 @@ static void launch_blockmul(const Chunks& c, const double* S, int lds_, const do
                             bool accumulate) {
   constexpr int p = 4 * P4;
   constexpr int ldS = p + ((34 - (p % 32)) % 32);
-  const size_t sm = sizeof(double) * (size_t)64 * ldS;
+  const size_t sm = sizeof(double) * (size_t)32 * ldS;
   static bool attr_done = false;
   if (sm > 64 * 1024 && !attr_done) {
     HIPCHK(hipFuncSetAttribute((const void*)k_blockmul_mfma<P4>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1039,6 +1255,27 @@ __global__ void k_block_axpby(double* __restrict__ Y, int ldy, double a, const d
 void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m) {
   if (n <= 0 || m <= 0) return;
   hipLaunchKernelGGL(k_block_axpby, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, Y, ldy, a, X, ldx, b,
+                     (int64_t)n, m);
+}
+// one Chebyshev step fused: r -= ad ; d = a * dinv .* r + b * d ; z += d
+__global__ void k_cheb_update(double* __restrict__ r, const double* __restrict__ ad, double* __restrict__ d,
+                              double* __restrict__ z, int ldz, const double* __restrict__ dinv, double a, double b,
+                              int64_t n, int m) {
+  const int64_t tot = n * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / m;
+    const int j = (int)(e - i * m);
+    const double rv = r[e] - ad[e];
+    const double dv = a * dinv[i] * rv + b * d[e];
+    r[e] = rv;
+    d[e] = dv;
+    z[i * ldz + j] += dv;
+  }
+}
+void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
+                 int n, int m) {
+  if (n <= 0 || m <= 0) return;
+  hipLaunchKernelGGL(k_cheb_update, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, r, ad, d, z, ldz, dinv, a, b,
                      (int64_t)n, m);
 }
 // Y[i][j] = a * d[i] * X[i][j] + b*Y[i][j]

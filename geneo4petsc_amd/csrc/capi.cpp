@@ -357,6 +357,11 @@ int GeneoSelfTestMFMA(void) {
     return -1;
   }
 }
+PetscErrorCode GeneoSetSpmvKind(int kind) {
+  bk::set_spmv_kind(kind);
+  return 0;
+}
+const char* GeneoSpmvKernelName(void) { return bk::spmv_kernel_name(); }
 PetscErrorCode GeneoSetMFMA(int enable) {
   bk::set_mfma(enable != 0);
   return 0;

@@ -24,6 +24,7 @@
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include "dense.h"
 
@@ -147,9 +148,7 @@ PC::~PC() { free_all(); }
 
 void PC::free_all() {
   bk::csr_free(dirL);
-  // neuE shares rowptr / val / rowblk with neuL: free only its own column array
-  if (neuE.col && neuE.col != neuL.col) bk::dfree(neuE.col);
-  neuE = bk::Csr();
+  bk::csr_free(neuE);
   bk::csr_free(neuL);
   if (ch.start) bk::chunks_free(ch);
   void* ptrs[] = {d_l2e, d_rt_ptr, d_rt_idx, d_send_idx, d_rv_ptr, d_rv_idx, d_rv_tgt, d_D, d_dinv1, d_dinvN, d_xe,
@@ -412,15 +411,10 @@ int PC::setup(const double* b_dev) {
   }
   auto t1 = clk::now();
   neuL = upload_blockdiag(neu, suboff, nullptr);
-  {  // same matrix with ext-space columns for the MATIS MatMult (shares rowptr / values / row blocks)
+  {  // same matrix with ext-space columns for the MATIS MatMult (own copy: the sliced layout embeds the columns)
     std::vector<int> l2e(nL);
     bk::d2h(l2e.data(), d_l2e, sizeof(int) * nL);
-    std::vector<int> colL((size_t)neuL.nnz);
-    bk::d2h(colL.data(), neuL.col, sizeof(int) * (size_t)neuL.nnz);
-    for (auto& c : colL) c = l2e[c];
-    neuE = neuL;
-    neuE.col = (int*)bk::alloc(sizeof(int) * std::max<size_t>(1, colL.size()));
-    bk::h2d(neuE.col, colL.data(), sizeof(int) * colL.size());
+    neuE = upload_blockdiag(neu, suboff, l2e.data());
   }
   dirL = upload_blockdiag(lvl1, suboff, nullptr);
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
@@ -800,7 +794,7 @@ int PC::eigen_lobpcg() {
     bk::d2h(hGA.data(), dGA, sizeof(double) * (size_t)ns * p * p);
     bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p * p);
     std::fill(hC.begin(), hC.end(), 0.0);
-    for (int s = 0; s < ns; ++s) {
+    auto rr_one = [&](int s) {
       std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
       std::vector<double> gb(hGB.begin() + (size_t)s * p * p, hGB.begin() + (size_t)(s + 1) * p * p);
       for (int a = 0; a < p; ++a)
@@ -811,7 +805,7 @@ int PC::eigen_lobpcg() {
       double* cs = hC.data() + (size_t)s * p * qout;
       if (frozen[s]) {  // converged subdomain: keep X, drop P (identity update)
         for (int j = 0; j < m; ++j) cs[(size_t)j * qout + j] = 1.0;
-        continue;
+        return;
       }
       std::vector<double> th, C;
       const int r = dense::gen_eig_rr(ga, gb, p, nfix, opt.rr_drop, th, C);
@@ -826,6 +820,19 @@ int PC::eigen_lobpcg() {
         } else {
           lam[(size_t)s * m + j] = 1e300;  // fewer independent directions than m
         }
+      }
+    };
+    {  // the per-subdomain projected problems are independent: one host thread each (bounded)
+      const int nth = std::max(1, std::min(ns, (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+      if (nth == 1) {
+        for (int s = 0; s < ns; ++s) rr_one(s);
+      } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; ++t)
+          th.emplace_back([&, t]() {
+            for (int s = t; s < ns; s += nth) rr_one(s);
+          });
+        for (auto& x : th) x.join();
       }
     }
     bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
@@ -884,12 +891,18 @@ int PC::eigen_lobpcg() {
       fprintf(stderr, " | lam0 %.6e %.6e .. %.6e\n", lam[0], lam[1], lam[nev_s[0] - 1]);
     }
     if (all_done || it == opt.eps_max_it) break;
-    for (size_t e = 0; e < locked.size(); ++e) mask[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-    bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
-    bk::block_colscale(ch, cr, m, m, dmask);
-    bk::block_colscale(ch, S + m, p3, m, dmask);
-    bk::block_colscale(ch, AS + m, p3, m, dmask);
-    bk::block_colscale(ch, BS + m, p3, m, dmask);
+    bool any_locked = false;
+    for (size_t e = 0; e < locked.size(); ++e) {
+      mask[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+      if (mask[e] == 0.0) any_locked = true;
+    }
+    if (any_locked) {
+      bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
+      bk::block_colscale(ch, cr, m, m, dmask);
+      bk::block_colscale(ch, S + m, p3, m, dmask);
+      bk::block_colscale(ch, AS + m, p3, m, dmask);
+      bk::block_colscale(ch, BS + m, p3, m, dmask);
+    }
     // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
     double rho = 1.0 / sigma;
     bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
@@ -897,10 +910,9 @@ int PC::eigen_lobpcg() {
     for (int k = 1; k < opt.cheb_degree; ++k) {
       bk::spmm_strided(neuL, cd, m, cad, m, m, nullptr, nullptr);         // A d
       info.eig_spmm++;
-      bk::block_axpby(cr, m, -1.0, cad, m, 1.0, nL, m);                   // r -= A d
       const double rho_new = 1.0 / (2.0 * sigma - rho);
-      bk::block_rowscale(cd, m, cr, m, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
-      bk::block_axpby(W, p3, 1.0, cd, m, 1.0, nL, m);                     // z += d
+      // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
+      bk::cheb_update(cr, cad, cd, W, p3, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
       rho = rho_new;
     }
     applyA(W, AS + 2 * m);

@@ -75,54 +75,153 @@ inline void lu_solve(const std::vector<double>& a, int n, const std::vector<int>
   }
 }
 
-// Symmetric eigen-decomposition A = V diag(w) V^T (cyclic Jacobi; A is n x n row-major and is
-// destroyed).  Eigenvalues ascending in w, eigenvectors in the COLUMNS of v (row-major n x n).
-// Jacobi is chosen for its high relative accuracy on the tiny, well-scaled projected problems.
+// Symmetric eigen-decomposition A = V diag(w) V^T: Householder tridiagonalisation followed by the
+// implicit QL iteration (the classical tred2 / tql2 pair).  A is n x n row-major and is destroyed.
+// Eigenvalues ascending in w, eigenvectors in the COLUMNS of v (row-major n x n).
 inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::vector<double>& v) {
-  v.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) v[i * n + i] = 1.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int i = 0; i < n; ++i) {
-      diag += a[i * n + i] * a[i * n + i];
-      for (int j = i + 1; j < n; ++j) off += a[i * n + j] * a[i * n + j];
-    }
-    if (off <= 1e-32 * (diag + off) || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = a[p * n + q];
-        if (apq == 0.0) continue;
-        const double app = a[p * n + p], aqq = a[q * n + q];
-        if (std::fabs(apq) < 1e-300) continue;
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {  // rotate columns p,q of A
-          const double akp = a[k * n + p], akq = a[k * n + q];
-          a[k * n + p] = c * akp - s * akq;
-          a[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {  // rotate rows p,q of A
-          const double apk = a[p * n + k], aqk = a[q * n + k];
-          a[p * n + k] = c * apk - s * aqk;
-          a[q * n + k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = v[k * n + p], vkq = v[k * n + q];
-          v[k * n + p] = c * vkp - s * vkq;
-          v[k * n + q] = s * vkp + c * vkq;
-        }
+  v = a;  // work in v: v[i*n+j]
+  w.assign(n, 0.0);
+  std::vector<double> e(n, 0.0);
+  auto V = [&](int i, int j) -> double& { return v[(size_t)i * n + j]; };
+  if (n == 0) return;
+  // ---- tred2
+  for (int j = 0; j < n; ++j) w[j] = V(n - 1, j);
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0.0, h = 0.0;
+    for (int k = 0; k < i; ++k) scale += std::fabs(w[k]);
+    if (scale == 0.0) {
+      e[i] = w[i - 1];
+      for (int j = 0; j < i; ++j) {
+        w[j] = V(i - 1, j);
+        V(i, j) = 0.0;
+        V(j, i) = 0.0;
       }
+    } else {
+      for (int k = 0; k < i; ++k) {
+        w[k] /= scale;
+        h += w[k] * w[k];
+      }
+      double f = w[i - 1];
+      double g = std::sqrt(h);
+      if (f > 0) g = -g;
+      e[i] = scale * g;
+      h -= f * g;
+      w[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0.0;
+      for (int j = 0; j < i; ++j) {
+        f = w[j];
+        V(j, i) = f;
+        g = e[j] + V(j, j) * f;
+        for (int k = j + 1; k <= i - 1; ++k) {
+          g += V(k, j) * w[k];
+          e[k] += V(k, j) * f;
+        }
+        e[j] = g;
+      }
+      f = 0.0;
+      for (int j = 0; j < i; ++j) {
+        e[j] /= h;
+        f += e[j] * w[j];
+      }
+      const double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * w[j];
+      for (int j = 0; j < i; ++j) {
+        f = w[j];
+        g = e[j];
+        for (int k = j; k <= i - 1; ++k) V(k, j) -= (f * e[k] + g * w[k]);
+        w[j] = V(i - 1, j);
+        V(i, j) = 0.0;
+      }
+    }
+    w[i] = h;
   }
+  for (int i = 0; i < n - 1; ++i) {
+    V(n - 1, i) = V(i, i);
+    V(i, i) = 1.0;
+    const double h = w[i + 1];
+    if (h != 0.0) {
+      for (int k = 0; k <= i; ++k) w[k] = V(k, i + 1) / h;
+      for (int j = 0; j <= i; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= i; ++k) g += V(k, i + 1) * V(k, j);
+        for (int k = 0; k <= i; ++k) V(k, j) -= g * w[k];
+      }
+    }
+    for (int k = 0; k <= i; ++k) V(k, i + 1) = 0.0;
+  }
+  for (int j = 0; j < n; ++j) {
+    w[j] = V(n - 1, j);
+    V(n - 1, j) = 0.0;
+  }
+  V(n - 1, n - 1) = 1.0;
+  e[0] = 0.0;
+  // ---- tql2
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  double f = 0.0, tst1 = 0.0;
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    tst1 = std::max(tst1, std::fabs(w[l]) + std::fabs(e[l]));
+    int m = l;
+    while (m < n) {
+      if (std::fabs(e[m]) <= eps * tst1) break;
+      ++m;
+    }
+    if (m >= n) m = n - 1;
+    if (m > l) {
+      int iter = 0;
+      do {
+        ++iter;
+        double g = w[l];
+        double p = (w[l + 1] - g) / (2.0 * e[l]);
+        double r = std::hypot(p, 1.0);
+        if (p < 0) r = -r;
+        w[l] = e[l] / (p + r);
+        w[l + 1] = e[l] * (p + r);
+        const double dl1 = w[l + 1];
+        double h = g - w[l];
+        for (int i = l + 2; i < n; ++i) w[i] -= h;
+        f += h;
+        p = w[m];
+        double c = 1.0, c2 = c, c3 = c;
+        const double el1 = e[l + 1];
+        double s = 0.0, s2 = 0.0;
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = std::hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * w[i] - s * g;
+          w[i + 1] = h + s * (c * g + s * w[i]);
+          for (int k = 0; k < n; ++k) {
+            h = V(k, i + 1);
+            V(k, i + 1) = s * V(k, i) + c * h;
+            V(k, i) = c * V(k, i) - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        w[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+    }
+    w[l] += f;
+    e[l] = 0.0;
+  }
+  // sort ascending
   std::vector<int> ord(n);
   for (int i = 0; i < n; ++i) ord[i] = i;
-  std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return a[x * n + x] < a[y * n + y]; });
-  w.resize(n);
-  std::vector<double> vs((size_t)n * n);
+  std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return w[x] < w[y]; });
+  std::vector<double> ws(n), vs((size_t)n * n);
   for (int j = 0; j < n; ++j) {
-    w[j] = a[ord[j] * n + ord[j]];
-    for (int k = 0; k < n; ++k) vs[k * n + j] = v[k * n + ord[j]];
+    ws[j] = w[ord[j]];
+    for (int k = 0; k < n; ++k) vs[(size_t)k * n + j] = v[(size_t)k * n + ord[j]];
   }
+  w.swap(ws);
   v.swap(vs);
 }
 

@@ -150,6 +150,8 @@ PetscErrorCode GeneoH2D(void* dst_dev, const void* src, size_t bytes);
 PetscErrorCode GeneoD2H(void* dst, const void* src_dev, size_t bytes);
 PetscErrorCode GeneoDeviceSync(void);
 int GeneoSelfTestMFMA(void);                     /* 0 = f64 MFMA lane maps as assumed */
+PetscErrorCode GeneoSetSpmvKind(int kind);       /* 0: LDS row-block SpMV kernel, 1: 64-row sliced kernel (default) */
+const char* GeneoSpmvKernelName(void);
 PetscErrorCode GeneoSetMFMA(int enable);         /* 0: run the plain-FMA twins of the MFMA kernels (validation) */
 
 /* ---- stand-alone kernels (parity tests and the roofline leg of bench.py) --------------------- */

@@ -257,6 +257,16 @@ void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* 
       Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
     }
 }
+void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
+                 int n, int m) {
+  for (int64_t i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const int64_t e = i * m + j;
+      r[e] -= ad[e];
+      d[e] = a * dinv[i] * r[e] + b * d[e];
+      z[i * ldz + j] += d[e];
+    }
+}
 void block_colscale(const Chunks& c, double* X, int ldx, int m, const double* cs) {
   for (int s = 0; s < c.nsub; ++s)
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
@@ -318,6 +328,8 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
   }
 }
 void set_mfma(bool) {}
+void set_spmv_kind(int) {}
+const char* spmv_kernel_name() { return "hostsim"; }
 int selftest_mfma_f64() { return 0; }
 void* event_create() { return nullptr; }
 void event_record(void*) {}

@@ -33,13 +33,18 @@ def test_mfma_lane_map(lib):
     assert lib.GeneoSelfTestMFMA() == 0
 
 
+@pytest.mark.parametrize("kind", [1, 0])
 @pytest.mark.parametrize("n,density,long_row", [(1, 1.0, None), (257, 0.02, None), (5000, 0.002, None),
-                                                (4000, 0.001, 17), (70000, 0.0001, None)])
-def test_spmv(lib, n, density, long_row):
+                                                (4000, 0.001, 17), (70000, 0.0001, None), (130, 0.6, None)])
+def test_spmv(lib, n, density, long_row, kind):
     from geneo4petsc_amd.pc import Spmv
     a = _rand_csr(n, density, 1, long_row)
     x = np.random.default_rng(2).random(n) - 0.5
-    y = Spmv(a, lib).apply(x)
+    lib.GeneoSetSpmvKind(kind)
+    try:
+        y = Spmv(a, lib).apply(x)
+    finally:
+        lib.GeneoSetSpmvKind(1)
     np.testing.assert_allclose(y, a @ x, rtol=1e-13, atol=1e-13)
 
 
@@ -55,7 +60,8 @@ def test_spmv_laplacian_7pt(lib):
     from geneo4petsc_amd.pc import Spmv
     a = decomp.global_matrix(decomp.grid_mesh(n=40, dim=3))
     x = np.random.default_rng(3).random(a.shape[0])
-    np.testing.assert_allclose(Spmv(a, lib).apply(x), a @ x, rtol=1e-13)
+    # rows of the Laplacian nearly cancel: compare with an absolute floor scaled by |A||x|
+    np.testing.assert_allclose(Spmv(a, lib).apply(x), a @ x, rtol=1e-13, atol=1e-14 * float(abs(a).max()) * 7)
 
 
 @pytest.mark.parametrize("m", [1, 16, 20, 32, 64])
