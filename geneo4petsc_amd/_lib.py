@@ -33,7 +33,8 @@ class GeneoInfo(C.Structure):
                                           "lvl2SetupETimeLoc", "lvl1ApplyTimeLoc", "lvl1ApplyScatterTimeLoc",
                                           "lvl1ApplyMinvTimeLoc", "lvl1ApplyGatherTimeLoc",
                                           "lvl1ApplyPrjFSTimeLoc", "lvl2ApplyTimeLoc", "lvl2ApplyZtTimeLoc",
-                                          "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")]
+                                          "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")] + \
+               [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
@@ -81,6 +82,7 @@ SYMBOLS = {
     "GeneoDeviceSync": (C.c_int, []),
     "GeneoSelfTestMFMA": (C.c_int, []),
     "GeneoSetMFMA": (C.c_int, [C.c_int]),
+    "GeneoTestAxpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int]),
     "GeneoSetSpmvKind": (C.c_int, [C.c_int]),
     "GeneoSpmvKernelName": (C.c_char_p, []),
     "GeneoSpmvCreate": (C.c_int, [C.POINTER(GeneoCsr), C.POINTER(C.c_void_p)]),

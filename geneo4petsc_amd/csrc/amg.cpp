@@ -1,0 +1,371 @@
+// Smoothed-aggregation AMG: host set-up + device V-cycle (see amg.h).
+#include "amg.h"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+#include <thread>
+
+#include "dense.h"
+
+namespace geneo {
+
+// ------------------------------------------------------------------------------ host sparse kernels
+static HostCsr transpose(const HostCsr& a, int ncols) {
+  HostCsr t;
+  t.n = ncols;
+  t.rowptr.assign(ncols + 1, 0);
+  for (int c : a.col) t.rowptr[c + 1]++;
+  for (int i = 0; i < ncols; ++i) t.rowptr[i + 1] += t.rowptr[i];
+  t.col.resize(a.col.size());
+  t.val.resize(a.val.size());
+  std::vector<int> fill(t.rowptr.begin(), t.rowptr.end() - 1);
+  for (int i = 0; i < a.n; ++i)
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int p = fill[a.col[k]]++;
+      t.col[p] = i;
+      t.val[p] = a.val[k];
+    }
+  return t;
+}
+
+// C = A * B (row-wise with a marker array), rows [r0, r1) only; columns sorted per row
+static void spgemm_rows(const HostCsr& a, const HostCsr& b, int ncols_b, int r0, int r1, std::vector<int>& crow_len,
+                        std::vector<std::vector<int>>& ccol, std::vector<std::vector<double>>& cval) {
+  std::vector<int> marker(ncols_b, -1);
+  std::vector<int> cols;
+  std::vector<double> vals;
+  for (int i = r0; i < r1; ++i) {
+    cols.clear();
+    vals.clear();
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int j = a.col[k];
+      const double av = a.val[k];
+      for (int l = b.rowptr[j]; l < b.rowptr[j + 1]; ++l) {
+        const int c = b.col[l];
+        if (marker[c] < 0) {
+          marker[c] = (int)cols.size();
+          cols.push_back(c);
+          vals.push_back(av * b.val[l]);
+        } else {
+          vals[marker[c]] += av * b.val[l];
+        }
+      }
+    }
+    std::vector<int> ord(cols.size());
+    for (size_t t = 0; t < ord.size(); ++t) ord[t] = (int)t;
+    std::sort(ord.begin(), ord.end(), [&](int x, int y) { return cols[x] < cols[y]; });
+    ccol[i].resize(cols.size());
+    cval[i].resize(cols.size());
+    for (size_t t = 0; t < ord.size(); ++t) {
+      ccol[i][t] = cols[ord[t]];
+      cval[i][t] = vals[ord[t]];
+    }
+    crow_len[i] = (int)cols.size();
+    for (int c : cols) marker[c] = -1;
+  }
+}
+
+static HostCsr spgemm(const HostCsr& a, const HostCsr& b, int ncols_b) {
+  const int n = a.n;
+  std::vector<int> len(n, 0);
+  std::vector<std::vector<int>> ccol(n);
+  std::vector<std::vector<double>> cval(n);
+  const int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  if (n < 20000 || nth == 1) {
+    spgemm_rows(a, b, ncols_b, 0, n, len, ccol, cval);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) {
+      const int r0 = (int)((int64_t)n * t / nth), r1 = (int)((int64_t)n * (t + 1) / nth);
+      th.emplace_back([&, r0, r1]() { spgemm_rows(a, b, ncols_b, r0, r1, len, ccol, cval); });
+    }
+    for (auto& x : th) x.join();
+  }
+  HostCsr c;
+  c.n = n;
+  c.rowptr.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) c.rowptr[i + 1] = c.rowptr[i] + len[i];
+  c.col.resize(c.rowptr[n]);
+  c.val.resize(c.rowptr[n]);
+  for (int i = 0; i < n; ++i) {
+    std::copy(ccol[i].begin(), ccol[i].end(), c.col.begin() + c.rowptr[i]);
+    std::copy(cval[i].begin(), cval[i].end(), c.val.begin() + c.rowptr[i]);
+  }
+  return c;
+}
+
+// Vanek-style aggregation inside one diagonal block [r0, r1): returns #aggregates, agg[i] local ids
+static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& agg) {
+  int na = 0;
+  for (int i = r0; i < r1; ++i) agg[i] = -1;
+  for (int i = r0; i < r1; ++i) {  // phase 1: a free node whose whole neighbourhood is free seeds an aggregate
+    if (agg[i] >= 0) continue;
+    bool ok = true;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int j = a.col[k];
+      if (j != i && a.val[k] != 0.0 && agg[j] >= 0) { ok = false; break; }
+    }
+    if (!ok) continue;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
+      if (a.val[k] != 0.0) agg[a.col[k]] = na;
+    agg[i] = na++;
+  }
+  std::vector<int> join(r1 - r0, -1);
+  for (int i = r0; i < r1; ++i) {  // phase 2: leftovers join the most strongly connected aggregate
+    if (agg[i] >= 0) continue;
+    double best = 0.0;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int j = a.col[k];
+      if (j != i && agg[j] >= 0 && std::fabs(a.val[k]) > best) {
+        best = std::fabs(a.val[k]);
+        join[i - r0] = agg[j];
+      }
+    }
+  }
+  for (int i = r0; i < r1; ++i)
+    if (agg[i] < 0 && join[i - r0] >= 0) agg[i] = join[i - r0];
+  for (int i = r0; i < r1; ++i)  // phase 3: isolated nodes
+    if (agg[i] < 0) agg[i] = na++;
+  return na;
+}
+
+static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
+  dinv.assign(a.n, 1.0);
+  double rho = 0.0;
+  for (int i = 0; i < a.n; ++i) {
+    double d = 0.0, row = 0.0;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      row += std::fabs(a.val[k]);
+      if (a.col[k] == i) d += a.val[k];
+    }
+    if (!(d > 0.0)) throw std::runtime_error("AMG: non-positive diagonal");
+    dinv[i] = 1.0 / d;
+    rho = std::max(rho, row / d);
+  }
+  return rho > 0 ? rho : 2.0;
+}
+
+void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm,
+                    std::vector<AmgLevelHost>& levels, std::vector<double>& coarse_inv,
+                    std::vector<int64_t>& coarse_base) {
+  levels.clear();
+  const int nsub = (int)suboff.size() - 1;
+  levels.emplace_back();
+  levels.back().A = A;
+  levels.back().suboff = suboff;
+  while (true) {
+    AmgLevelHost& L = levels.back();
+    L.rho = gershgorin_rho(L.A, L.dinv);
+    int maxblk = 0;
+    for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, L.suboff[s + 1] - L.suboff[s]);
+    if (maxblk <= prm.coarse_size || (int)levels.size() >= prm.max_levels) break;
+    // aggregation per subdomain block
+    const int n = L.A.n;
+    std::vector<int> agg(n, -1), csub(nsub + 1, 0);
+    for (int s = 0; s < nsub; ++s) {
+      const int na = aggregate_block(L.A, L.suboff[s], L.suboff[s + 1], agg);
+      for (int i = L.suboff[s]; i < L.suboff[s + 1]; ++i) agg[i] += csub[s];
+      csub[s + 1] = csub[s] + na;
+    }
+    const int nc = csub[nsub];
+    if (nc >= n) break;  // no coarsening possible
+    // tentative prolongator (piecewise constant) and its Jacobi smoothing  P = (I - w D^-1 A) P0
+    HostCsr P0;
+    P0.n = n;
+    P0.rowptr.resize(n + 1);
+    P0.col.resize(n);
+    P0.val.assign(n, 1.0);
+    for (int i = 0; i <= n; ++i) P0.rowptr[i] = i;
+    for (int i = 0; i < n; ++i) P0.col[i] = agg[i];
+    const double omega = 4.0 / (3.0 * L.rho);
+    HostCsr AP0 = spgemm(L.A, P0, nc);
+    HostCsr P;
+    P.n = n;
+    P.rowptr.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      bool has = false;
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k) {
+        double v = -omega * L.dinv[i] * AP0.val[k];
+        if (AP0.col[k] == agg[i]) { v += 1.0; has = true; }
+        P.col.push_back(AP0.col[k]);
+        P.val.push_back(v);
+      }
+      if (!has) {  // keep the tentative entry even if A*P0 has no entry there
+        P.col.push_back(agg[i]);
+        P.val.push_back(1.0);
+      }
+      P.rowptr[i + 1] = (int)P.col.size();
+    }
+    // sort the (rare) appended entry into place
+    for (int i = 0; i < n; ++i) {
+      const int a0 = P.rowptr[i], a1 = P.rowptr[i + 1];
+      for (int k = a1 - 1; k > a0 && P.col[k] < P.col[k - 1]; --k) {
+        std::swap(P.col[k], P.col[k - 1]);
+        std::swap(P.val[k], P.val[k - 1]);
+      }
+    }
+    HostCsr R = transpose(P, nc);
+    HostCsr AP = spgemm(L.A, P, nc);
+    HostCsr Ac = spgemm(R, AP, nc);
+    L.P = std::move(P);
+    L.R = std::move(R);
+    levels.emplace_back();
+    levels.back().A = std::move(Ac);
+    levels.back().suboff = csub;
+  }
+  // dense inverse of every coarsest block (SPD: Cholesky; tiny pivots regularised)
+  const AmgLevelHost& C = levels.back();
+  coarse_base.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) {
+    const int64_t m = C.suboff[s + 1] - C.suboff[s];
+    coarse_base[s + 1] = coarse_base[s] + m * m;
+  }
+  coarse_inv.assign((size_t)std::max<int64_t>(1, coarse_base[nsub]), 0.0);
+  auto invert = [&](int s) {
+    const int r0 = C.suboff[s], m = C.suboff[s + 1] - r0;
+    if (m == 0) return;
+    std::vector<double> a((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i)
+      for (int k = C.A.rowptr[r0 + i]; k < C.A.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (C.A.col[k] - r0)] += C.A.val[k];
+    for (int i = 0; i < m; ++i)
+      for (int j = i + 1; j < m; ++j) a[(size_t)i * m + j] = a[(size_t)j * m + i] = 0.5 * (a[(size_t)i * m + j] + a[(size_t)j * m + i]);
+    std::vector<double> l = a;
+    if (!dense::cholesky(l, m)) {
+      double tr = 0.0;
+      for (int i = 0; i < m; ++i) tr += a[(size_t)i * m + i];
+      l = a;
+      for (int i = 0; i < m; ++i) l[(size_t)i * m + i] += 1e-10 * tr / m;
+      if (!dense::cholesky(l, m)) throw std::runtime_error("AMG: coarsest block is not positive definite");
+    }
+    std::vector<double> e(m);
+    double* inv = coarse_inv.data() + coarse_base[s];
+    for (int j = 0; j < m; ++j) {
+      std::fill(e.begin(), e.end(), 0.0);
+      e[j] = 1.0;
+      dense::cholesky_solve(l, m, e.data());
+      for (int i = 0; i < m; ++i) inv[(size_t)i * m + j] = e[i];
+    }
+  };
+  {
+    const int nth = std::max(1, std::min(nsub, std::min(16, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        for (int s = t; s < nsub; s += nth) invert(s);
+      });
+    for (auto& x : th) x.join();
+  }
+}
+
+// ------------------------------------------------------------------------------ device V-cycle
+AmgDevice::~AmgDevice() { free_all(); }
+
+void AmgDevice::free_all() {
+  for (auto& L : lv) {
+    bk::csr_free(L.A);
+    bk::csr_free(L.P);
+    bk::csr_free(L.R);
+    bk::dfree(L.dinv); bk::dfree(L.b); bk::dfree(L.x); bk::dfree(L.r); bk::dfree(L.d); bk::dfree(L.ad);
+  }
+  lv.clear();
+  if (cch.start) bk::chunks_free(cch);
+  bk::dfree(d_inv);
+  bk::dfree(d_invbase);
+  d_inv = nullptr;
+  d_invbase = nullptr;
+}
+
+void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vector<double>& coarse_inv,
+                       const std::vector<int64_t>& coarse_base, const AmgParams& p, int max_m) {
+  free_all();
+  prm = p;
+  maxm = std::max(1, max_m);
+  double nnz0 = 0.0, nnzt = 0.0;
+  for (size_t l = 0; l < levels.size(); ++l) {
+    const AmgLevelHost& H = levels[l];
+    Lvl L;
+    L.n = H.A.n;
+    L.rho = H.rho;
+    L.A = bk::csr_upload(H.A.n, H.A.rowptr.data(), H.A.col.data(), H.A.val.data());
+    if (l + 1 < levels.size()) {
+      L.P = bk::csr_upload(H.P.n, H.P.rowptr.data(), H.P.col.data(), H.P.val.data());
+      L.R = bk::csr_upload(H.R.n, H.R.rowptr.data(), H.R.col.data(), H.R.val.data());
+    }
+    const size_t blk = sizeof(double) * std::max<size_t>(1, (size_t)L.n * maxm);
+    L.dinv = (double*)bk::alloc(sizeof(double) * std::max(1, L.n));
+    bk::h2d(L.dinv, H.dinv.data(), sizeof(double) * L.n);
+    L.r = (double*)bk::alloc(blk);
+    L.d = (double*)bk::alloc(blk);
+    if (p.smooth_degree > 1) L.ad = (double*)bk::alloc(blk);
+    if (l > 0) {
+      L.b = (double*)bk::alloc(blk);
+      L.x = (double*)bk::alloc(blk);
+    }
+    if (l == 0) nnz0 = (double)H.A.val.size();
+    nnzt += (double)H.A.val.size();
+    lv.push_back(L);
+  }
+  opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;
+  const AmgLevelHost& C = levels.back();
+  cch = bk::chunks_upload((int)C.suboff.size() - 1, C.suboff.data());
+  d_inv = (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, coarse_inv.size()));
+  bk::h2d(d_inv, coarse_inv.data(), sizeof(double) * coarse_inv.size());
+  d_invbase = (int64_t*)bk::alloc(sizeof(int64_t) * coarse_base.size());
+  bk::h2d(d_invbase, coarse_base.data(), sizeof(int64_t) * coarse_base.size());
+}
+
+void AmgDevice::applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m) {
+  if (m == 1 && ldx == 1 && ldy == 1) bk::spmv(a, X, Y);
+  else bk::spmm_strided(a, X, ldx, Y, ldy, m, nullptr, nullptr);
+}
+
+// Chebyshev-Jacobi smoothing of A x = b on [rho/ratio, 1.1 rho] (degree 1 = damped Jacobi)
+void AmgDevice::smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int m, bool zero_guess) {
+  const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  const int n = L.n;
+  double* r = L.r;
+  double* d = L.d;
+  if (zero_guess) {
+    bk::block_axpby(r, m, 1.0, B, ldb, 0.0, n, m);                         // r = b
+    bk::block_rowscale(d, m, r, m, L.dinv, 1.0 / theta, 0.0, n, m);        // d = Dinv r / theta
+    bk::block_axpby(X, ldx, 1.0, d, m, 0.0, n, m);                         // x = d
+  } else {
+    applyA(L.A, X, ldx, r, m, m);                                          // r = b - A x
+    bk::block_axpby(r, m, 1.0, B, ldb, -1.0, n, m);
+    bk::block_rowscale(d, m, r, m, L.dinv, 1.0 / theta, 0.0, n, m);
+    bk::block_axpby(X, ldx, 1.0, d, m, 1.0, n, m);                         // x += d
+  }
+  double rho = 1.0 / sigma;
+  for (int k = 1; k < prm.smooth_degree; ++k) {
+    applyA(L.A, d, m, L.ad, m, m);                                         // A d
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    bk::cheb_update(r, L.ad, d, X, ldx, L.dinv, 2.0 * rho_new / delta, rho_new * rho, n, m);
+    rho = rho_new;
+  }
+}
+
+void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m) {
+  Lvl& L = lv[l];
+  if (l == (int)lv.size() - 1) {
+    bk::dense_sym_apply(cch, d_inv, d_invbase, B, ldb, X, ldx, m);
+    return;
+  }
+  smooth(L, B, ldb, X, ldx, m, true);                                      // pre-smoothing, zero guess
+  applyA(L.A, X, ldx, L.r, m, m);                                          // r = b - A x
+  bk::block_axpby(L.r, m, 1.0, B, ldb, -1.0, L.n, m);
+  Lvl& C = lv[l + 1];
+  applyA(L.R, L.r, m, C.b, m, m);                                          // restrict
+  cycle(l + 1, C.b, m, C.x, m, m);
+  applyA(L.P, C.x, m, L.d, m, m);                                          // prolong + correct
+  bk::block_axpby(X, ldx, 1.0, L.d, m, 1.0, L.n, m);
+  smooth(L, B, ldb, X, ldx, m, false);                                     // post-smoothing
+}
+
+void AmgDevice::vcycle(const double* B, int ldb, double* X, int ldx, int m) {
+  if (m > maxm) throw std::runtime_error("AMG: block wider than the hierarchy was allocated for");
+  cycle(0, B, ldb, X, ldx, m);
+}
+
+}  // namespace geneo

@@ -1,0 +1,68 @@
+// Smoothed-aggregation AMG hierarchy for the block-diagonal local matrices (one independent
+// hierarchy per subdomain, stored concatenated so every level is ONE CSR / one launch).
+//
+// Role: preconditioner INSIDE the batched local PCG that replaces the reference's MUMPS solve
+// (geneo.cpp:94-160,:1995) and inside LOBPCG (replacing ARPACK's shift-invert, geneo.cpp:626-744).
+// The operator the outer Krylov method sees is still A_Dir^-1 to -dls1_ksp_rtol; AMG only changes how
+// fast the inner iteration gets there.  Set-up (aggregation, Galerkin products) runs once on the host.
+#pragma once
+#include <vector>
+
+#include "backend.h"
+#include "core.h"
+
+namespace geneo {
+
+struct AmgParams {
+  int max_levels = 10;
+  int coarse_size = 600;      // stop coarsening when every subdomain block is at most this large
+  int smooth_degree = 1;      // Chebyshev-Jacobi smoother degree (1 = damped Jacobi)
+  double smooth_ratio = 4.0;  // smoothing interval [rho/ratio, 1.1 rho]
+};
+
+struct AmgLevelHost {
+  HostCsr A, P, R;            // P: n x nc, R = P^T
+  std::vector<double> dinv;
+  std::vector<int> suboff;    // nsub+1 row offsets of the subdomain blocks on this level
+  double rho = 2.0;           // Gershgorin bound of D^-1 A
+};
+
+// Host set-up: levels[0].A = the given matrix.  The last level carries no P/R; its dense inverse per
+// subdomain is returned in coarse_inv (row-major, concatenated; coarse_base[s] = element offset).
+void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm,
+                    std::vector<AmgLevelHost>& levels, std::vector<double>& coarse_inv,
+                    std::vector<int64_t>& coarse_base);
+
+// Device hierarchy + V-cycle on row-major blocks of m vectors (m = 1: SpMV kernels).
+class AmgDevice {
+ public:
+  ~AmgDevice();
+  void upload(const std::vector<AmgLevelHost>& levels, const std::vector<double>& coarse_inv,
+              const std::vector<int64_t>& coarse_base, const AmgParams& prm, int max_m);
+  // X = V(B) with zero initial guess; B, X: n0 x m row-major with leading dimensions ldb / ldx
+  void vcycle(const double* B, int ldb, double* X, int ldx, int m);
+  int nlevels() const { return (int)lv.size(); }
+  double operator_complexity() const { return opc; }
+  void free_all();
+
+ private:
+  struct Lvl {
+    bk::Csr A, P, R;
+    double* dinv = nullptr;
+    double *b = nullptr, *x = nullptr, *r = nullptr, *d = nullptr, *ad = nullptr;  // n x max_m work blocks
+    int n = 0;
+    double rho = 2.0;
+  };
+  std::vector<Lvl> lv;
+  bk::Chunks cch;              // chunks of the coarsest level (per subdomain)
+  double* d_inv = nullptr;
+  int64_t* d_invbase = nullptr;
+  AmgParams prm;
+  int maxm = 1;
+  double opc = 1.0;
+  void applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m);
+  void smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int m, bool zero_guess);
+  void cycle(int l, const double* B, int ldb, double* X, int ldx, int m);
+};
+
+}  // namespace geneo

@@ -98,7 +98,14 @@ void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int
 //   0 rz(parity 0) 1 rz(parity 1) 2 pAp 3 rr 4 alpha 5 beta 6 active(0/1) 7 rr0
 void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, double* p, const double* b,
               const double* dinv);                                       // x=0 r=b z=dinv.*r p=z
-void seg_pap(const Chunks& c, const double* p, const double* q);         // chunk partials of p.q
+void seg_pap(const Chunks& c, const double* p, const double* q);         // chunk partials of p.q (slot 0)
+void seg_partial(const Chunks& c, const double* x, const double* y, int slot);  // chunk partials of x.y
+void cg_set_rz(const Chunks& c, double* sc);   // sc rz slots <- partial slot 1 (after cg_start with dinv == nullptr)
+// (cg_start / cg_update accept dinv == nullptr: z and the r.z partial are then left to the caller,
+//  who applies its own preconditioner and calls seg_partial(c, r, z, 1))
+// X_s = Inv_s B_s for symmetric dense blocks Inv_s (n_s x n_s at inv + base[s]); blocks of m vectors
+void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, const double* B, int ldb, double* X,
+                     int ldx, int m);
 void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, double* z, const double* p,
                const double* q, const double* dinv);                     // alpha; x,r,z; partials
 void cg_direction(const Chunks& c, double* sc, int parity, double* p, const double* z, double tol2);

@@ -630,18 +630,20 @@ __global__ __launch_bounds__(256) void k_cg_start(const int* __restrict__ start,
   double rz = 0.0, rr = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     const double rv = b[a + i];
-    const double zv = dinv[a + i] * rv;
     x[a + i] = 0.0;
     r[a + i] = rv;
-    z[a + i] = zv;
-    p[a + i] = zv;
-    rz += rv * zv;
+    if (dinv) {
+      const double zv = dinv[a + i] * rv;
+      z[a + i] = zv;
+      p[a + i] = zv;
+      rz += rv * zv;
+    }
     rr += rv * rv;
   }
   rz = block_sum_256(rz, sm);
   rr = block_sum_256(rr, sm);
   if (threadIdx.x == 0) {
-    part[(int64_t)1 * nchunk + c] = rz;
+    if (dinv) part[(int64_t)1 * nchunk + c] = rz;
     part[(int64_t)2 * nchunk + c] = rr;
   }
 }
@@ -663,6 +665,25 @@ void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, doub
                      c.partial, c.nchunk);
   hipLaunchKernelGGL(k_cg_start2, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk,
                      sc, c.nsub);
+}
+void seg_partial(const Chunks& c, const double* x, const double* y, int slot) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_seg_dot1, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, x, y, c.partial, c.nchunk,
+                     slot);
+}
+// second half of cg_start when the caller preconditions itself: p = z, rz slots from partial slot 1
+__global__ void k_cg_start3(const int* __restrict__ subptr, const double* __restrict__ part, int nchunk,
+                            double* __restrict__ sc, int nsub) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsub) return;
+  const double rz = sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
+  sc[(int64_t)s * 8 + 0] = rz;
+  sc[(int64_t)s * 8 + 1] = rz;
+}
+void cg_set_rz(const Chunks& c, double* sc) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_cg_start3, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk, sc,
+                     c.nsub);
 }
 void seg_pap(const Chunks& c, const double* p, const double* q) {
   if (c.nchunk == 0) return;
@@ -689,17 +710,19 @@ __global__ __launch_bounds__(256) void k_cg_update(const int* __restrict__ start
   for (int i = threadIdx.x; i < n; i += 256) {
     const double xv = x[a + i] + alpha * p[a + i];
     const double rv = r[a + i] - alpha * q[a + i];
-    const double zv = dinv[a + i] * rv;
     x[a + i] = xv;
     r[a + i] = rv;
-    z[a + i] = zv;
-    nrz += rv * zv;
+    if (dinv) {
+      const double zv = dinv[a + i] * rv;
+      z[a + i] = zv;
+      nrz += rv * zv;
+    }
     nrr += rv * rv;
   }
   nrz = block_sum_256(nrz, sm);
   nrr = block_sum_256(nrr, sm);
   if (threadIdx.x == 0) {
-    part[(int64_t)1 * nchunk + c] = nrz;
+    if (dinv) part[(int64_t)1 * nchunk + c] = nrz;
     part[(int64_t)2 * nchunk + c] = nrr;
     if (c == c0) {
       sc[(int64_t)s * 8 + 2] = pap;
@@ -1448,6 +1471,32 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
   if (c.nchunk == 0) return;
   hipLaunchKernelGGL(k_z_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, Z, zbase,
                      ksub, zoff, yE, wL, accumulate ? 1 : 0);
+}
+
+// X_s = Inv_s B_s, Inv_s symmetric (read column-wise = coalesced).  One workgroup per chunk of rows.
+__global__ __launch_bounds__(256) void k_dense_sym_apply(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                         const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                         const double* __restrict__ inv, const int64_t* __restrict__ base,
+                                                         const double* __restrict__ B, int ldb, double* __restrict__ X,
+                                                         int ldx, int m) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int s0 = suboff[s];
+  const int ns = suboff[s + 1] - s0;
+  const double* A = inv + base[s];
+  for (int e = threadIdx.x; e < nrows * m; e += 256) {
+    const int rr = e % nrows, j = e / nrows;   // consecutive threads -> consecutive rows (coalesced A reads)
+    const int i = row0 - s0 + rr;
+    double acc = 0.0;
+    for (int k = 0; k < ns; ++k) acc += A[(int64_t)k * ns + i] * B[(int64_t)(s0 + k) * ldb + j];
+    X[(int64_t)(row0 + rr) * ldx + j] = acc;
+  }
+}
+void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, const double* B, int ldb, double* X,
+                     int ldx, int m) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_dense_sym_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, inv,
+                     base, B, ldb, X, ldx, m);
 }
 
 // =============================================================================== self test / events

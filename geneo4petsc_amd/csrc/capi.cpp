@@ -290,6 +290,7 @@ PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* o) {
   o->lvl1ApplyPrjFSTimeLoc = i.lvl1ApplyPrjFSTimeLoc; o->lvl2ApplyTimeLoc = i.lvl2ApplyTimeLoc;
   o->lvl2ApplyZtTimeLoc = i.lvl2ApplyZtTimeLoc; o->lvl2ApplyEinvTimeLoc = i.lvl2ApplyEinvTimeLoc;
   o->lvl2ApplyZTimeLoc = i.lvl2ApplyZTimeLoc; o->setupTime = i.setupTime; o->solveTime = i.solveTime;
+  o->amg_levels = i.amg_levels; o->amg_operator_complexity = i.amg_operator_complexity; o->amgSetupTime = i.amgSetupTime;
   return 0;
 }
 static int copy_out(const std::vector<double>& v, double* out, int cap) {
@@ -356,6 +357,12 @@ int GeneoSelfTestMFMA(void) {
     g_global_err = e.what();
     return -1;
   }
+}
+PetscErrorCode GeneoTestAxpby(double* y_dev, const double* x_dev, double a, double b, int n) {
+  GUARD_BEGIN
+  bk::axpby(y_dev, a, x_dev, b, n);
+  GUARD_END((PC) nullptr)
+  return 0;
 }
 PetscErrorCode GeneoSetSpmvKind(int kind) {
   bk::set_spmv_kind(kind);

@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <thread>
 
+#include "amg.h"
 #include "dense.h"
 
 namespace geneo {
@@ -118,6 +119,20 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   if (key == "-dls1_ksp_rtol") return dbl(o.dls1_rtol);
   if (key == "-dls1_ksp_max_it") return integer(o.dls1_max_it);
   if (key == "-dls1_check") return integer(o.dls1_check);
+  if (key == "-dls1_pc_type") {
+    if (value != "amg" && value != "jacobi") return "unsupported -dls1_pc_type " + value;
+    o.dls1_pc = value;
+    return "";
+  }
+  if (key == "-els2_pc_type") {
+    if (value != "amg" && value != "cheb") return "unsupported -els2_pc_type " + value;
+    o.els2_pc = value;
+    return "";
+  }
+  if (key == "-amg_coarse_size") return integer(o.amg_coarse_size);
+  if (key == "-amg_smooth_degree") return integer(o.amg_smooth_degree);
+  if (key == "-amg_smooth_ratio") return dbl(o.amg_smooth_ratio);
+  if (key == "-amg_max_levels") return integer(o.amg_max_levels);
   if (key == "-ksp_type") {
     if (value != "cg" && value != "gmres") return "unsupported -ksp_type " + value;
     o.ksp_type = value;
@@ -147,6 +162,9 @@ int PC::fail(const std::string& msg) {
 PC::~PC() { free_all(); }
 
 void PC::free_all() {
+  delete amg1;
+  delete amgN;
+  amg1 = amgN = nullptr;
   bk::csr_free(dirL);
   bk::csr_free(neuE);
   bk::csr_free(neuL);
@@ -382,6 +400,47 @@ static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const s
   return bk::csr_upload(n, rp.data(), col.data(), val.data());
 }
 
+// AMG hierarchy of a block-diagonal matrix given by its per-subdomain blocks (host set-up)
+int PC::build_amg(const std::vector<const HostCsr*>& mats, int max_m, AmgDevice** out) {
+  const int ns = (int)mats.size();
+  HostCsr blk;
+  blk.n = nL;
+  blk.rowptr.assign(nL + 1, 0);
+  size_t nnz = 0;
+  for (auto* m : mats) nnz += m->val.size();
+  blk.col.reserve(nnz);
+  blk.val.reserve(nnz);
+  for (int s = 0; s < ns; ++s) {
+    const HostCsr& m = *mats[s];
+    for (int i = 0; i < m.n; ++i) {
+      for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) {
+        blk.col.push_back(suboff[s] + m.col[k]);
+        blk.val.push_back(m.val[k]);
+      }
+      blk.rowptr[suboff[s] + i + 1] = (int)blk.col.size();
+    }
+  }
+  AmgParams ap;
+  ap.coarse_size = opt.amg_coarse_size;
+  ap.smooth_degree = opt.amg_smooth_degree;
+  ap.smooth_ratio = opt.amg_smooth_ratio;
+  ap.max_levels = opt.amg_max_levels;
+  std::vector<AmgLevelHost> levels;
+  std::vector<double> cinv;
+  std::vector<int64_t> cbase;
+  try {
+    amg_setup_host(blk, suboff, ap, levels, cinv, cbase);
+    delete *out;
+    *out = new AmgDevice();
+    (*out)->upload(levels, cinv, cbase, ap, max_m);
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  info.amg_levels = (*out)->nlevels();
+  info.amg_operator_complexity = (*out)->operator_complexity();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------ setup
 int PC::setup(const double* b_dev) {
   auto t0 = clk::now();
@@ -451,6 +510,19 @@ int PC::setup(const double* b_dev) {
     cheb_lmax = lmax > 0 ? lmax : 2.0;
     for (int i = 0; i < nL; ++i) dg[i] = 1.0 / dg[i];
     bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
+  }
+  {
+    auto ta = clk::now();
+    if (opt.dls1_pc == "amg")
+      if (int rc = build_amg(lvl1, 1, &amg1)) return rc;
+    if (opt.lvl2 && opt.els2_pc == "amg") {
+      const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
+      const int want = nev_try + std::max(4, nev_try / 4);
+      const int max_m = opt.eps_block > 0 ? opt.eps_block : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));
+      if (int rc = build_amg(neu, max_m, &amgN)) return rc;
+    }
+    bk::sync();
+    info.amgSetupTime = secs(ta, clk::now());
   }
   bk::sync();
   info.lvl1SetupMinvTimeLoc = secs(t1, clk::now());
@@ -526,19 +598,31 @@ int PC::matmult(const double* x, double* y) {
 void PC::local_solve(double* wL) {
   if (opt.lvl1RAS) bk::xmy(wL, wL, d_D, nL);
   const int ns = (int)subs.size();
+  const bool use_amg = (opt.dls1_pc == "amg") && amg1;
   double* x = d_xL;  // solution
-  bk::cg_start(ch, d_cg_sc, x, d_cg_r, d_cg_z, d_cg_p, wL, d_dinv1);
+  const double* dinv = use_amg ? nullptr : d_dinv1;
+  bk::cg_start(ch, d_cg_sc, x, d_cg_r, d_cg_z, d_cg_p, wL, dinv);
+  if (use_amg) {
+    amg1->vcycle(d_cg_r, 1, d_cg_z, 1, 1);
+    bk::seg_partial(ch, d_cg_r, d_cg_z, 1);
+    bk::cg_set_rz(ch, d_cg_sc);
+    bk::copy(d_cg_p, d_cg_z, nL);
+  }
   const double tol2 = opt.dls1_rtol * opt.dls1_rtol;
   std::vector<double> sc((size_t)8 * std::max(1, ns));
   int it = 0;
   int parity = 0;
-  const int check = std::max(1, opt.dls1_check);
+  const int check = std::max(1, use_amg ? std::min(4, opt.dls1_check) : opt.dls1_check);
   bool done = false;
   while (!done && it < opt.dls1_max_it) {
     for (int k = 0; k < check && it < opt.dls1_max_it; ++k, ++it) {
       bk::spmv(dirL, d_cg_p, d_cg_q);
       bk::seg_pap(ch, d_cg_p, d_cg_q);
-      bk::cg_update(ch, d_cg_sc, parity, x, d_cg_r, d_cg_z, d_cg_p, d_cg_q, d_dinv1);
+      bk::cg_update(ch, d_cg_sc, parity, x, d_cg_r, d_cg_z, d_cg_p, d_cg_q, dinv);
+      if (use_amg) {
+        amg1->vcycle(d_cg_r, 1, d_cg_z, 1, 1);
+        bk::seg_partial(ch, d_cg_r, d_cg_z, 1);
+      }
       bk::cg_direction(ch, d_cg_sc, parity, d_cg_p, d_cg_z, tol2);
       parity ^= 1;
     }
@@ -888,7 +972,8 @@ int PC::eigen_lobpcg() {
         for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
         fprintf(stderr, " %.2e", mx);
       }
-      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e\n", lam[0], lam[1], lam[nev_s[0] - 1]);
+      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1],
+              (opt.els2_pc == "amg" && amgN) ? "amg" : "cheb");
     }
     if (all_done || it == opt.eps_max_it) break;
     bool any_locked = false;
@@ -903,17 +988,23 @@ int PC::eigen_lobpcg() {
       bk::block_colscale(ch, AS + m, p3, m, dmask);
       bk::block_colscale(ch, BS + m, p3, m, dmask);
     }
-    // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
-    double rho = 1.0 / sigma;
-    bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
-    bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                       // z = d
-    for (int k = 1; k < opt.cheb_degree; ++k) {
-      bk::spmm_strided(neuL, cd, m, cad, m, m, nullptr, nullptr);         // A d
-      info.eig_spmm++;
-      const double rho_new = 1.0 / (2.0 * sigma - rho);
-      // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
-      bk::cheb_update(cr, cad, cd, W, p3, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
-      rho = rho_new;
+    if (opt.els2_pc == "amg" && amgN) {
+      // W = T r : one smoothed-aggregation V-cycle of A_Neu on the whole block (~ shift-invert at sigma = 0)
+      amgN->vcycle(cr, m, W, p3, m);
+      info.eig_spmm += 3;
+    } else {
+      // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
+      double rho = 1.0 / sigma;
+      bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
+      bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                       // z = d
+      for (int k = 1; k < opt.cheb_degree; ++k) {
+        bk::spmm_strided(neuL, cd, m, cad, m, m, nullptr, nullptr);         // A d
+        info.eig_spmm++;
+        const double rho_new = 1.0 / (2.0 * sigma - rho);
+        // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
+        bk::cheb_update(cr, cad, cd, W, p3, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
+        rho = rho_new;
+      }
     }
     applyA(W, AS + 2 * m);
     applyB(W, BS + 2 * m);

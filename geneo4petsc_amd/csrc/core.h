@@ -8,6 +8,7 @@
 #include "backend.h"
 
 namespace geneo {
+class AmgDevice;
 
 struct HostCsr {
   int n = 0;
@@ -37,7 +38,11 @@ struct Options {
   // -dls1_ : local "direct" solve replaced by batched Jacobi-PCG driven to a tight tolerance
   double dls1_rtol = 1e-12;
   int dls1_max_it = 20000;
-  int dls1_check = 16;     // host convergence poll period (iterations)
+  int dls1_check = 16;     // host convergence poll period (iterations; 4 with the AMG preconditioner)
+  // inner preconditioners: "amg" = smoothed-aggregation V-cycle (default), "jacobi" / "cheb" = round-1 baseline
+  std::string dls1_pc = "amg", els2_pc = "amg";
+  int amg_coarse_size = 600, amg_smooth_degree = 1, amg_max_levels = 10;
+  double amg_smooth_ratio = 4.0;
   // Krylov driver (counterpart of the PETSc KSP the reference calls at driver:1240)
   std::string ksp_type = "gmres";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e5;
@@ -59,6 +64,8 @@ struct Info {                 // public counters / timers of geneoContext (hdr/g
          lvl2ApplyZTimeLoc = 0;
   double setupTime = 0, solveTime = 0;
   long long spmv_calls = 0;
+  int amg_levels = 0;
+  double amg_operator_complexity = 0.0, amgSetupTime = 0.0;
 };
 
 struct KspResult {
@@ -139,6 +146,9 @@ class PC {
   bool E_chol = true;
   std::vector<double> h_yE;
   double cheb_lmax = 2.0;
+  AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
+  AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
+  int build_amg(const std::vector<const HostCsr*>& mats, int max_m, AmgDevice** out);
 
   int fail(const std::string& msg);
   int build_layout();

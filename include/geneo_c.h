@@ -132,6 +132,8 @@ typedef struct {
   double lvl1ApplyTimeLoc, lvl1ApplyScatterTimeLoc, lvl1ApplyMinvTimeLoc, lvl1ApplyGatherTimeLoc;
   double lvl1ApplyPrjFSTimeLoc, lvl2ApplyTimeLoc, lvl2ApplyZtTimeLoc, lvl2ApplyEinvTimeLoc, lvl2ApplyZTimeLoc;
   double setupTime, solveTime;
+  int amg_levels;                       /* levels of the inner AMG hierarchy (0 = not used) */
+  double amg_operator_complexity, amgSetupTime;
 } GeneoInfo;
 PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* info);
 /* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */
@@ -150,6 +152,8 @@ PetscErrorCode GeneoH2D(void* dst_dev, const void* src, size_t bytes);
 PetscErrorCode GeneoD2H(void* dst, const void* src_dev, size_t bytes);
 PetscErrorCode GeneoDeviceSync(void);
 int GeneoSelfTestMFMA(void);                     /* 0 = f64 MFMA lane maps as assumed */
+/* y = a x + b y on device vectors (calibration kernel of the HBM-traffic PMC passes) */
+PetscErrorCode GeneoTestAxpby(double* y_dev, const double* x_dev, double a, double b, int n);
 PetscErrorCode GeneoSetSpmvKind(int kind);       /* 0: LDS row-block SpMV kernel, 1: 64-row sliced kernel (default) */
 const char* GeneoSpmvKernelName(void);
 PetscErrorCode GeneoSetMFMA(int enable);         /* 0: run the plain-FMA twins of the MFMA kernels (validation) */

@@ -146,11 +146,36 @@ void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, doub
   for (int s = 0; s < c.nsub; ++s) {
     double rz = 0, rr = 0;
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
-      x[i] = 0; r[i] = b[i]; z[i] = dinv[i] * r[i]; p[i] = z[i];
-      rz += r[i] * z[i]; rr += r[i] * r[i];
+      x[i] = 0; r[i] = b[i];
+      if (dinv) { z[i] = dinv[i] * r[i]; p[i] = z[i]; rz += r[i] * z[i]; }
+      rr += r[i] * r[i];
     }
     double* q = sc + (int64_t)s * 8;
     q[0] = q[1] = rz; q[2] = 0; q[3] = rr; q[4] = q[5] = 0; q[6] = rr > 0 ? 1.0 : 0.0; q[7] = rr;
+  }
+}
+void seg_partial(const Chunks& c, const double* x, const double* y, int slot) {
+  for (int s = 0; s < c.nsub; ++s) {
+    double t = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += x[i] * y[i];
+    if (slot == 0) c.partial[s] = t;
+    else c.partial[c.nsub + 2 * s + (slot - 1)] = t;
+  }
+}
+void cg_set_rz(const Chunks& c, double* sc) {
+  for (int s = 0; s < c.nsub; ++s) sc[(int64_t)s * 8] = sc[(int64_t)s * 8 + 1] = c.partial[c.nsub + 2 * s];
+}
+void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, const double* B, int ldb, double* X,
+                     int ldx, int m) {
+  for (int s = 0; s < c.nsub; ++s) {
+    const int s0 = c.suboff[s], ns = c.suboff[s + 1] - s0;
+    const double* A = inv + base[s];
+    for (int i = 0; i < ns; ++i)
+      for (int j = 0; j < m; ++j) {
+        double acc = 0;
+        for (int k = 0; k < ns; ++k) acc += A[(int64_t)k * ns + i] * B[(int64_t)(s0 + k) * ldb + j];
+        X[(int64_t)(s0 + i) * ldx + j] = acc;
+      }
   }
 }
 void seg_pap(const Chunks& c, const double* p, const double* q) {
@@ -170,12 +195,11 @@ void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, do
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
       x[i] += alpha * p[i];
       r[i] -= alpha * q[i];
-      z[i] = dinv[i] * r[i];
-      nrz += r[i] * z[i];
+      if (dinv) { z[i] = dinv[i] * r[i]; nrz += r[i] * z[i]; }
       nrr += r[i] * r[i];
     }
     t[2] = pap; t[4] = alpha;
-    c.partial[c.nsub + 2 * s] = nrz;
+    if (dinv) c.partial[c.nsub + 2 * s] = nrz;
     c.partial[c.nsub + 2 * s + 1] = nrr;
   }
 }

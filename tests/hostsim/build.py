@@ -14,8 +14,9 @@ OUT = os.path.join(HERE, "libgeneopc_hostsim.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, "core.cpp"), os.path.join(CSRC, "capi.cpp"), os.path.join(HERE, "backend_host.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("core.h", "backend.h", "dense.h")] + \
+    srcs = [os.path.join(CSRC, "core.cpp"), os.path.join(CSRC, "amg.cpp"), os.path.join(CSRC, "capi.cpp"),
+            os.path.join(HERE, "backend_host.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("core.h", "backend.h", "dense.h", "amg.h")] + \
         [os.path.join(ROOT, "include", "geneo_c.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

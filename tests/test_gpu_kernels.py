@@ -15,12 +15,16 @@ def lib():
 
 def _rand_csr(n, density, seed, long_row=None):
     rng = np.random.default_rng(seed)
-    a = sp.random(n, n, density=density, random_state=seed, format="csr")
-    a = a + sp.diags(rng.random(n) + 1.0)
+    nnz = max(1, int(density * n * n))
+    rows = rng.integers(0, n, size=nnz)           # (sp.random is quadratic in n on this scipy)
+    cols = rng.integers(0, n, size=nnz)
+    a = sp.csr_matrix((rng.random(nnz) - 0.5, (rows, cols)), shape=(n, n)) + sp.diags(rng.random(n) + 1.0)
     if long_row is not None:
         a = a.tolil()
         a[long_row, :] = rng.random(n)
         a = a.tocsr()
+    a = a.tocsr()
+    a.sum_duplicates()
     a.sort_indices()
     return a
 

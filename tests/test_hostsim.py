@@ -23,6 +23,16 @@ def test_modes(lib, lvl, ksp, overlap):
     cases.compare_with_oracle(lib, 12, (2, 2, 2), overlap, argv)
 
 
+def test_multilevel_amg_inner_preconditioner(lib):
+    """Two-level smoothed-aggregation hierarchy inside the local PCG and inside LOBPCG: same outer
+    operator as the oracle's exact LU (parity unchanged), far fewer inner iterations than Jacobi."""
+    base = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.19", "-geneo_cut", "8", "-ksp_type", "cg"] + TIGHT
+    _, amg = cases.compare_with_oracle(lib, 20, (2, 2, 2), 1, base + ["-amg_coarse_size", "200"])
+    _, jac = cases.compare_with_oracle(lib, 20, (2, 2, 2), 1, base + ["-dls1_pc_type", "jacobi", "-els2_pc_type", "cheb"])
+    assert amg["amg_levels"] >= 2 and jac["amg_levels"] == 0
+    assert amg["dls1_iterations"] * 3 < jac["dls1_iterations"]
+
+
 def test_dirichlet_built_from_matis(lib):
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "cg"] + TIGHT
     cases.compare_with_oracle(lib, 10, (2, 2, 1), 1, argv, with_dir=False)
