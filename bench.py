@@ -118,7 +118,7 @@ def cpu_baseline(args, doms):
 def geneo_argv(args):
     return ["-geneo_lvl", args.lvl, "-geneo_tau", str(args.tau), "-geneo_cut", str(args.cut),
             "-els2_eps_tol", str(args.eps_tol), "-ksp_type", "cg", "-ksp_rtol", str(args.rtol),
-            "-dls1_ksp_rtol", str(args.dls1_rtol)]
+            "-dls1_ksp_rtol", str(args.dls1_rtol), "-dls1_pc_type", args.dls1_pc, "-els2_pc_type", args.els2_pc]
 
 
 def main():
@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--eps-tol", type=float, default=1e-3, help="reference default, geneo.cpp:658")
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc KSP default rtol")
     ap.add_argument("--dls1-rtol", type=float, default=1e-10)
+    ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
+    ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
     ap.add_argument("--cpu-sample-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +196,10 @@ def main():
     for i in range(args.warmup):
         step(pcs[i])
         pcs[i].destroy()
-    lib.GeneoSpmvProfileStart(8)
+    # roofline kernel = the CSR SpMV on the fine (subdomain) matrices; the small coarse-level launches of the
+    # inner AMG hierarchy use the same kernel but are latency-, not bandwidth-bound: time the fine ones only
+    fine_bytes = sum(d.a_dir.nnz for d in doms) * 12.0 + sum(len(d.l2g) for d in doms) * 20.0
+    lib.GeneoSpmvProfileStart(4, C.c_double(0.5 * fine_bytes))
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -236,7 +241,8 @@ def main():
                        "grid": n, "dof": n ** 3, "subdomains": nb, "overlap": args.overlap},
             "setup_s": setup_s, "solve_s": solve_s, "setup_plus_solve_s": setup_s + solve_s,
             "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
-            "local_solve_cg_iterations": info["dls1_iterations"], "host_prep_s": prep_s,
+            "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
+            "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
             "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs_rank / HBM_PEAK_GBS, "traffic": None,
                          "kernel": lib.GeneoSpmvKernelName().decode(), "launches_timed": int(nsamp.value),

@@ -89,7 +89,7 @@ SYMBOLS = {
     "GeneoSpmvApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "GeneoSpmvTime": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),
     "GeneoSpmvDestroy": (C.c_int, [C.POINTER(C.c_void_p)]),
-    "GeneoSpmvProfileStart": (C.c_int, [C.c_int]),
+    "GeneoSpmvProfileStart": (C.c_int, [C.c_int, C.c_double]),
     "GeneoSpmvProfileStop": (C.c_int, [c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoSpmmApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "GeneoBlockKernel": (C.c_int, [C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p,

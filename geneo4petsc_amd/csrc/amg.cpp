@@ -2,7 +2,11 @@
 #include "amg.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <thread>
 
@@ -29,69 +33,66 @@ static HostCsr transpose(const HostCsr& a, int ncols) {
   return t;
 }
 
-// C = A * B (row-wise with a marker array), rows [r0, r1) only; columns sorted per row
-static void spgemm_rows(const HostCsr& a, const HostCsr& b, int ncols_b, int r0, int r1, std::vector<int>& crow_len,
-                        std::vector<std::vector<int>>& ccol, std::vector<std::vector<double>>& cval) {
-  std::vector<int> marker(ncols_b, -1);
-  std::vector<int> cols;
-  std::vector<double> vals;
-  for (int i = r0; i < r1; ++i) {
-    cols.clear();
-    vals.clear();
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
-      const int j = a.col[k];
-      const double av = a.val[k];
-      for (int l = b.rowptr[j]; l < b.rowptr[j + 1]; ++l) {
-        const int c = b.col[l];
-        if (marker[c] < 0) {
-          marker[c] = (int)cols.size();
-          cols.push_back(c);
-          vals.push_back(av * b.val[l]);
-        } else {
-          vals[marker[c]] += av * b.val[l];
-        }
-      }
-    }
-    std::vector<int> ord(cols.size());
-    for (size_t t = 0; t < ord.size(); ++t) ord[t] = (int)t;
-    std::sort(ord.begin(), ord.end(), [&](int x, int y) { return cols[x] < cols[y]; });
-    ccol[i].resize(cols.size());
-    cval[i].resize(cols.size());
-    for (size_t t = 0; t < ord.size(); ++t) {
-      ccol[i][t] = cols[ord[t]];
-      cval[i][t] = vals[ord[t]];
-    }
-    crow_len[i] = (int)cols.size();
-    for (int c : cols) marker[c] = -1;
-  }
-}
-
+// C = A * B, two passes (symbolic row counts, then numeric fill into preallocated arrays) with one
+// marker array per thread; rows are split into contiguous ranges over host threads; columns unsorted.
 static HostCsr spgemm(const HostCsr& a, const HostCsr& b, int ncols_b) {
   const int n = a.n;
-  std::vector<int> len(n, 0);
-  std::vector<std::vector<int>> ccol(n);
-  std::vector<std::vector<double>> cval(n);
-  const int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-  if (n < 20000 || nth == 1) {
-    spgemm_rows(a, b, ncols_b, 0, n, len, ccol, cval);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t) {
-      const int r0 = (int)((int64_t)n * t / nth), r1 = (int)((int64_t)n * (t + 1) / nth);
-      th.emplace_back([&, r0, r1]() { spgemm_rows(a, b, ncols_b, r0, r1, len, ccol, cval); });
-    }
-    for (auto& x : th) x.join();
-  }
   HostCsr c;
   c.n = n;
   c.rowptr.assign(n + 1, 0);
-  for (int i = 0; i < n; ++i) c.rowptr[i + 1] = c.rowptr[i] + len[i];
+  int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  if (n < 20000) nth = 1;
+  auto range = [&](int t, int& r0, int& r1) {
+    r0 = (int)((int64_t)n * t / nth);
+    r1 = (int)((int64_t)n * (t + 1) / nth);
+  };
+  auto run = [&](const std::function<void(int)>& f) {
+    if (nth == 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) th.emplace_back(f, t);
+    for (auto& x : th) x.join();
+  };
+  run([&](int t) {  // symbolic
+    int r0, r1;
+    range(t, r0, r1);
+    std::vector<int> marker(ncols_b, -1);
+    for (int i = r0; i < r1; ++i) {
+      int cnt = 0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int j = a.col[k];
+        for (int l = b.rowptr[j]; l < b.rowptr[j + 1]; ++l)
+          if (marker[b.col[l]] != i) { marker[b.col[l]] = i; ++cnt; }
+      }
+      c.rowptr[i + 1] = cnt;
+    }
+  });
+  for (int i = 0; i < n; ++i) c.rowptr[i + 1] += c.rowptr[i];
   c.col.resize(c.rowptr[n]);
   c.val.resize(c.rowptr[n]);
-  for (int i = 0; i < n; ++i) {
-    std::copy(ccol[i].begin(), ccol[i].end(), c.col.begin() + c.rowptr[i]);
-    std::copy(cval[i].begin(), cval[i].end(), c.val.begin() + c.rowptr[i]);
-  }
+  run([&](int t) {  // numeric
+    int r0, r1;
+    range(t, r0, r1);
+    std::vector<int> marker(ncols_b, -1);
+    for (int i = r0; i < r1; ++i) {
+      const int base = c.rowptr[i];
+      int cnt = 0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int j = a.col[k];
+        const double av = a.val[k];
+        for (int l = b.rowptr[j]; l < b.rowptr[j + 1]; ++l) {
+          const int cc = b.col[l];
+          if (marker[cc] < base) {
+            marker[cc] = base + cnt;
+            c.col[base + cnt] = cc;
+            c.val[base + cnt] = av * b.val[l];
+            ++cnt;
+          } else {
+            c.val[marker[cc]] += av * b.val[l];
+          }
+        }
+      }
+    }
+  });
   return c;
 }
 
@@ -161,6 +162,12 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, L.suboff[s + 1] - L.suboff[s]);
     if (maxblk <= prm.coarse_size || (int)levels.size() >= prm.max_levels) break;
     // aggregation per subdomain block
+    const bool dbg = getenv("GENEO_DEBUG") != nullptr;
+    auto tnow = []() { return std::chrono::high_resolution_clock::now(); };
+    auto tsec = [](std::chrono::high_resolution_clock::time_point a, std::chrono::high_resolution_clock::time_point b) {
+      return std::chrono::duration<double>(b - a).count();
+    };
+    auto t_0 = tnow();
     const int n = L.A.n;
     std::vector<int> agg(n, -1), csub(nsub + 1, 0);
     for (int s = 0; s < nsub; ++s) {
@@ -179,35 +186,45 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     for (int i = 0; i <= n; ++i) P0.rowptr[i] = i;
     for (int i = 0; i < n; ++i) P0.col[i] = agg[i];
     const double omega = 4.0 / (3.0 * L.rho);
+    auto t_1 = tnow();
     HostCsr AP0 = spgemm(L.A, P0, nc);
+    auto t_2 = tnow();
     HostCsr P;
     P.n = n;
     P.rowptr.assign(n + 1, 0);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i) {  // row sizes: the entries of A*P0 plus the tentative one if absent
       bool has = false;
-      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k) {
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k)
+        if (AP0.col[k] == agg[i]) has = true;
+      P.rowptr[i + 1] = P.rowptr[i] + (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
+    }
+    P.col.resize(P.rowptr[n]);
+    P.val.resize(P.rowptr[n]);
+    for (int i = 0; i < n; ++i) {
+      int q = P.rowptr[i];
+      bool has = false;
+      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k, ++q) {
         double v = -omega * L.dinv[i] * AP0.val[k];
         if (AP0.col[k] == agg[i]) { v += 1.0; has = true; }
-        P.col.push_back(AP0.col[k]);
-        P.val.push_back(v);
+        P.col[q] = AP0.col[k];
+        P.val[q] = v;
       }
-      if (!has) {  // keep the tentative entry even if A*P0 has no entry there
-        P.col.push_back(agg[i]);
-        P.val.push_back(1.0);
-      }
-      P.rowptr[i + 1] = (int)P.col.size();
-    }
-    // sort the (rare) appended entry into place
-    for (int i = 0; i < n; ++i) {
-      const int a0 = P.rowptr[i], a1 = P.rowptr[i + 1];
-      for (int k = a1 - 1; k > a0 && P.col[k] < P.col[k - 1]; --k) {
-        std::swap(P.col[k], P.col[k - 1]);
-        std::swap(P.val[k], P.val[k - 1]);
+      if (!has) {
+        P.col[q] = agg[i];
+        P.val[q] = 1.0;
       }
     }
+    auto t_3 = tnow();
     HostCsr R = transpose(P, nc);
+    auto t_4 = tnow();
     HostCsr AP = spgemm(L.A, P, nc);
+    auto t_5 = tnow();
     HostCsr Ac = spgemm(R, AP, nc);
+    auto t_6 = tnow();
+    if (dbg)
+      fprintf(stderr, "[amg] level n %d -> %d nnz %zu -> %zu | agg %.3f AP0 %.3f P %.3f Rt %.3f AP %.3f RAP %.3f s\n", n, nc,
+              L.A.val.size(), Ac.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, t_3), tsec(t_3, t_4),
+              tsec(t_4, t_5), tsec(t_5, t_6));
     L.P = std::move(P);
     L.R = std::move(R);
     levels.emplace_back();
@@ -327,6 +344,11 @@ void AmgDevice::smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int
   const int n = L.n;
   double* r = L.r;
   double* d = L.d;
+  if (prm.smooth_degree <= 1) {  // damped Jacobi: one fused launch (+ one SpMV when the guess is non zero)
+    if (!zero_guess) applyA(L.A, X, ldx, r, m, m);
+    bk::jacobi_step(X, ldx, B, ldb, r, L.dinv, 1.0 / theta, n, m, zero_guess);
+    return;
+  }
   if (zero_guess) {
     bk::block_axpby(r, m, 1.0, B, ldb, 0.0, n, m);                         // r = b
     bk::block_rowscale(d, m, r, m, L.dinv, 1.0 / theta, 0.0, n, m);        // d = Dinv r / theta

@@ -54,7 +54,7 @@ void csr_free(Csr& a);
 void spmv(const Csr& a, const double* x, double* y);                    // y = A x
 // In-situ timing of the SpMV launches issued between start and stop: every `every`-th launch is
 // bracketed by two HIP events on the backend stream (no host sync until stop).
-void spmv_profile_start(int every);
+void spmv_profile_start(int every, double min_bytes);   // only launches moving >= min_bytes algorithmic bytes
 void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
@@ -124,6 +124,9 @@ void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double 
 // Y = a * d .* X + b * Y  (row scaling by d[i])
 void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,
                     int m);
+// damped-Jacobi step: zero_guess ? X = w*dinv.*B : X += w*dinv.*(B - AX)   (AX contiguous n x m)
+void jacobi_step(double* X, int ldx, const double* B, int ldb, const double* AX, const double* dinv, double w, int n,
+                 int m, bool zero_guess);
 // fused Chebyshev step on contiguous n x m blocks (z strided): r -= ad ; d = a*dinv.*r + b*d ; z += d
 void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
                  int n, int m);

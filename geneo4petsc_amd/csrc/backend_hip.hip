@@ -285,13 +285,15 @@ void set_spmv_kind(int kind) { g_spmv_kind = kind ? 1 : 0; }
 struct SpmvProf {
   bool on = false;
   int every = 1;
+  double min_bytes = 0.0;
   long long nlaunch = 0;
   std::vector<hipEvent_t> e0, e1;
   std::vector<double> bytes;
 };
 static SpmvProf g_prof;
-void spmv_profile_start(int every) {
+void spmv_profile_start(int every, double min_bytes) {
   g_prof.on = true;
+  g_prof.min_bytes = min_bytes;
   g_prof.every = every < 1 ? 1 : every;
   g_prof.nlaunch = 0;
   g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
@@ -318,7 +320,9 @@ void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, l
 void spmv(const Csr& a, const double* x, double* y) {
   if (a.n == 0) return;
   const int per = (a.nblk + 7) / 8;
-  const bool sample = g_prof.on && (g_prof.nlaunch++ % g_prof.every == 0) && g_prof.e0.size() < 20000;
+  const double abytes = (double)a.nnz * 12.0 + ((double)a.n + 1.0) * 4.0 + (double)a.n * 16.0;
+  const bool sample = g_prof.on && abytes >= g_prof.min_bytes && (g_prof.nlaunch++ % g_prof.every == 0) &&
+                      g_prof.e0.size() < 20000;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (sample) {
     HIPCHK(hipEventCreate(&e0));
@@ -342,7 +346,7 @@ void spmv(const Csr& a, const double* x, double* y) {
     g_prof.e0.push_back(e0);
     g_prof.e1.push_back(e1);
     // algorithmic bytes: nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)
-    g_prof.bytes.push_back((double)a.nnz * 12.0 + ((double)a.n + 1.0) * 4.0 + (double)a.n * 16.0);
+    g_prof.bytes.push_back(abytes);
   }
 }
 
@@ -1279,6 +1283,24 @@ void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double 
   if (n <= 0 || m <= 0) return;
   hipLaunchKernelGGL(k_block_axpby, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, Y, ldy, a, X, ldx, b,
                      (int64_t)n, m);
+}
+__global__ void k_jacobi_step(double* __restrict__ X, int ldx, const double* __restrict__ B, int ldb,
+                              const double* __restrict__ AX, const double* __restrict__ dinv, double w, int64_t n,
+                              int m, int zero_guess) {
+  const int64_t tot = n * m;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / m;
+    const int j = (int)(e - i * m);
+    const double bv = B[i * ldb + j];
+    if (zero_guess) X[i * ldx + j] = w * dinv[i] * bv;
+    else X[i * ldx + j] += w * dinv[i] * (bv - AX[e]);
+  }
+}
+void jacobi_step(double* X, int ldx, const double* B, int ldb, const double* AX, const double* dinv, double w, int n,
+                 int m, bool zero_guess) {
+  if (n <= 0 || m <= 0) return;
+  hipLaunchKernelGGL(k_jacobi_step, dim3(gridv((int64_t)n * m)), dim3(256), 0, g_stream, X, ldx, B, ldb, AX, dinv, w,
+                     (int64_t)n, m, zero_guess ? 1 : 0);
 }
 // one Chebyshev step fused: r -= ad ; d = a * dinv .* r + b * d ; z += d
 __global__ void k_cheb_update(double* __restrict__ r, const double* __restrict__ ad, double* __restrict__ d,

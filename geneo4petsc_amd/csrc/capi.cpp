@@ -404,8 +404,8 @@ PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x, double* y, int reps, 
   GUARD_END((PC) nullptr)
   return 0;
 }
-PetscErrorCode GeneoSpmvProfileStart(int every) {
-  bk::spmv_profile_start(every);
+PetscErrorCode GeneoSpmvProfileStart(int every, double min_bytes) {
+  bk::spmv_profile_start(every, min_bytes);
   return 0;
 }
 PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {

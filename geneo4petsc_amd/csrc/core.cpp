@@ -940,6 +940,13 @@ int PC::eigen_lobpcg() {
   std::vector<int> nev_s(ns);
   for (int s = 0; s < ns; ++s) nev_s[s] = std::min(nev_try, (int)subs[s].l2g.size());
   for (it = 0; it <= opt.eps_max_it; ++it) {
+    // the A X / B X blocks are carried by recurrence (A S C); refresh them explicitly every few
+    // iterations so that rounding drift (eps * ||A|| ||x|| per update, large for high-contrast
+    // operators) cannot accumulate into the residual
+    if (it > 0 && it % 8 == 0) {
+      applyA(S, AS);
+      applyB(S, BS);
+    }
     // residual into the W slot, convergence test
     bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
     double* W = S + 2 * m;

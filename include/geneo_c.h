@@ -167,7 +167,7 @@ PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x_dev, double* y_dev, in
 PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h);
 /* in-situ timing of every `every`-th CSR SpMV launch the library issues (solve loops included):
  * HIP events on the launch stream; stop returns the summed kernel ms and algorithmic bytes. */
-PetscErrorCode GeneoSpmvProfileStart(int every);
+PetscErrorCode GeneoSpmvProfileStart(int every, double min_bytes);  /* launches moving < min_bytes are skipped */
 PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
 /* Y = post.*(A (pre.*X)), row-major n x m blocks */
 PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, int m, const double* pre_dev,

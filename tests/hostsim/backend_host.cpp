@@ -50,7 +50,7 @@ void spmv(const Csr& a, const double* x, double* y) {
     y[i] = s;
   }
 }
-void spmv_profile_start(int) {}
+void spmv_profile_start(int, double) {}
 void spmv_profile_stop(double* a, double* b, long long* c, long long* d) {
   if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; if (d) *d = 0;
 }
@@ -279,6 +279,15 @@ void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* 
     for (int j = 0; j < m; ++j) {
       const double xv = a * d[i] * X[i * ldx + j];
       Y[i * ldy + j] = (b == 0.0) ? xv : xv + b * Y[i * ldy + j];
+    }
+}
+void jacobi_step(double* X, int ldx, const double* B, int ldb, const double* AX, const double* dinv, double w, int n,
+                 int m, bool zero_guess) {
+  for (int64_t i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const double bv = B[i * ldb + j];
+      if (zero_guess) X[i * ldx + j] = w * dinv[i] * bv;
+      else X[i * ldx + j] += w * dinv[i] * (bv - AX[i * m + j]);
     }
 }
 void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
