@@ -199,7 +199,7 @@ def main():
     # roofline kernel = the CSR SpMV on the fine (subdomain) matrices; the small coarse-level launches of the
     # inner AMG hierarchy use the same kernel but are latency-, not bandwidth-bound: time the fine ones only
     fine_bytes = sum(d.a_dir.nnz for d in doms) * 12.0 + sum(len(d.l2g) for d in doms) * 20.0
-    lib.GeneoSpmvProfileStart(4, C.c_double(0.5 * fine_bytes))
+    lib.GeneoSpmvProfileStart(4, C.c_double(0.9 * fine_bytes))
     barrier()
     t0 = time.perf_counter()
     last = None

@@ -14,8 +14,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "backend.h"
@@ -135,40 +137,55 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   a.nblk = (int)blk.size() - 1;
   a.rowblk = (int*)alloc(sizeof(int) * blk.size());
   h2d(a.rowblk, blk.data(), sizeof(int) * blk.size());
-  // 64-row slices, k-major, padded per slice (long rows excluded)
+  // 64-row slices, k-major, padded per slice (long rows excluded); built with host threads
   {
     const int ns = (n + 63) / 64;
     std::vector<int64_t> sp(ns + 1, 0);
     std::vector<int> longr;
-    for (int s = 0; s < ns; ++s) {
-      int w = 0;
-      for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
-        const int len = h_rowptr[i + 1] - h_rowptr[i];
-        if (len > SELL_LONG) longr.push_back(i);
-        else w = std::max(w, len);
+    const int nth = (ns > 4096) ? std::max(1, std::min(16, (int)std::thread::hardware_concurrency())) : 1;
+    auto par = [&](const std::function<void(int, int)>& f) {
+      if (nth == 1) { f(0, ns); return; }
+      std::vector<std::thread> th;
+      for (int t = 0; t < nth; ++t)
+        th.emplace_back(f, (int)((int64_t)ns * t / nth), (int)((int64_t)ns * (t + 1) / nth));
+      for (auto& x : th) x.join();
+    };
+    par([&](int s0, int s1) {
+      for (int s = s0; s < s1; ++s) {
+        int w = 0;
+        for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
+          const int len = h_rowptr[i + 1] - h_rowptr[i];
+          if (len <= SELL_LONG) w = std::max(w, len);
+        }
+        sp[s + 1] = (int64_t)64 * w;
       }
-      sp[s + 1] = sp[s] + (int64_t)64 * w;
-    }
-    std::vector<int> sc((size_t)std::max<int64_t>(1, sp[ns]), 0);
-    std::vector<double> sv((size_t)std::max<int64_t>(1, sp[ns]), 0.0);
-    for (int s = 0; s < ns; ++s) {
-      const int w = (int)((sp[s + 1] - sp[s]) / 64);
-      for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
-        const int len = h_rowptr[i + 1] - h_rowptr[i];
-        const int li = i - 64 * s;
-        const bool is_long = len > SELL_LONG;
-        for (int k = 0; k < w; ++k) {
-          const int64_t e = sp[s] + (int64_t)64 * k + li;
-          if (!is_long && k < len) {
-            sc[e] = h_col[h_rowptr[i] + k];
-            sv[e] = h_val[h_rowptr[i] + k];
-          } else {
-            sc[e] = h_col[h_rowptr[i]] * 0 + (len > 0 ? h_col[h_rowptr[i]] : 0);  // any valid column
-            sv[e] = 0.0;
+    });
+    for (int i = 0; i < n; ++i)
+      if (h_rowptr[i + 1] - h_rowptr[i] > SELL_LONG) longr.push_back(i);
+    for (int s = 0; s < ns; ++s) sp[s + 1] += sp[s];
+    std::vector<int> sc((size_t)std::max<int64_t>(1, sp[ns]));
+    std::vector<double> sv((size_t)std::max<int64_t>(1, sp[ns]));
+    par([&](int s0, int s1) {
+      for (int s = s0; s < s1; ++s) {
+        const int w = (int)((sp[s + 1] - sp[s]) / 64);
+        for (int li = 0; li < 64; ++li) {
+          const int i = 64 * s + li;
+          const int len = (i < n) ? h_rowptr[i + 1] - h_rowptr[i] : 0;
+          const bool use = (i < n) && len <= SELL_LONG;
+          const int padc = (i < n && len > 0) ? h_col[h_rowptr[i]] : 0;  // any valid column for the padding
+          for (int k = 0; k < w; ++k) {
+            const int64_t e = sp[s] + (int64_t)64 * k + li;
+            if (use && k < len) {
+              sc[e] = h_col[h_rowptr[i] + k];
+              sv[e] = h_val[h_rowptr[i] + k];
+            } else {
+              sc[e] = padc;
+              sv[e] = 0.0;
+            }
           }
         }
       }
-    }
+    });
     a.nslice = ns;
     a.sl_nnz = sp[ns];
     a.sl_ptr = (int64_t*)alloc(sizeof(int64_t) * (ns + 1));

@@ -45,8 +45,9 @@ def test_heat_high_contrast(lib):
     gen = dict(heat=True, kappa_max=100.0, interp="minmax")
     a0 = ["-geneo_lvl", "ASM,0", "-ksp_type", "cg"] + TIGHT
     a1 = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.015", "-geneo_cut", "12", "-ksp_type", "cg"] + TIGHT
-    its0, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a0, gen=gen)
-    its1, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a1, gen=gen)
+    # contrast 1e6: E inherits the conditioning of A, so the coarse operator action is compared to 1e-7
+    its0, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a0, gen=gen, aptol=1e-7)
+    its1, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a1, gen=gen, aptol=1e-7)
     assert its1 <= its0
 
 
