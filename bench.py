@@ -228,6 +228,19 @@ def main():
         setup_s, solve_s = info["setupTime"], info["solveTime"]
         agg_gbs = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
     gbs_rank = local["spmv_bytes"] / max(local["spmv_ms"], 1e-9) * 1e-6
+    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated as the guide prescribes:
+    # scripts/pmc_spmv.py + pmc_report.py, result committed under profiles/); only quoted when this run's
+    # matrix is the profiled one
+    traffic, traffic_src = None, None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_spmv_hbm_traffic_pmc.json")))
+        kname = lib.GeneoSpmvKernelName().decode()
+        alg = by_sum.value / max(1, nsamp.value)
+        if kname in prof and abs(prof[kname]["algorithmic_bytes"] - alg) <= 0.01 * alg:
+            traffic = prof[kname]["traffic_bytes_corrected"]
+            traffic_src = "profiles/r01_spmv_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except Exception:
+        pass
     if rank == 0:
         out = {
             "metric": "GenEO-PCG setup+solve sec and SpMV GB/s, 3D Laplacian 50M DoF, 1/2/4/8 GPUs",
@@ -244,7 +257,7 @@ def main():
             "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
             "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
             "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs_rank / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs_rank / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": lib.GeneoSpmvKernelName().decode(), "launches_timed": int(nsamp.value),
                          "launches_total": int(nlaunch.value),
                          "avg_launch_ms": ms_sum.value / max(1, nsamp.value),

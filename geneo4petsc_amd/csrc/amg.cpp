@@ -280,7 +280,7 @@ AmgDevice::~AmgDevice() { free_all(); }
 
 void AmgDevice::free_all() {
   for (auto& L : lv) {
-    bk::csr_free(L.A);
+    if (L.own_A) bk::csr_free(L.A);
     bk::csr_free(L.P);
     bk::csr_free(L.R);
     bk::dfree(L.dinv); bk::dfree(L.b); bk::dfree(L.x); bk::dfree(L.r); bk::dfree(L.d); bk::dfree(L.ad);
@@ -294,7 +294,7 @@ void AmgDevice::free_all() {
 }
 
 void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vector<double>& coarse_inv,
-                       const std::vector<int64_t>& coarse_base, const AmgParams& p, int max_m) {
+                       const std::vector<int64_t>& coarse_base, const AmgParams& p, int max_m, const bk::Csr* fine_dev) {
   free_all();
   prm = p;
   maxm = std::max(1, max_m);
@@ -304,7 +304,12 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
     Lvl L;
     L.n = H.A.n;
     L.rho = H.rho;
-    L.A = bk::csr_upload(H.A.n, H.A.rowptr.data(), H.A.col.data(), H.A.val.data());
+    if (l == 0 && fine_dev) {
+      L.A = *fine_dev;
+      L.own_A = false;
+    } else {
+      L.A = bk::csr_upload(H.A.n, H.A.rowptr.data(), H.A.col.data(), H.A.val.data());
+    }
     if (l + 1 < levels.size()) {
       L.P = bk::csr_upload(H.P.n, H.P.rowptr.data(), H.P.col.data(), H.P.val.data());
       L.R = bk::csr_upload(H.R.n, H.R.rowptr.data(), H.R.col.data(), H.R.val.data());

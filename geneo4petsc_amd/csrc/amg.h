@@ -37,8 +37,9 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
 class AmgDevice {
  public:
   ~AmgDevice();
+  // fine_dev: the level-0 matrix if it already lives in HBM (borrowed, not freed), else nullptr
   void upload(const std::vector<AmgLevelHost>& levels, const std::vector<double>& coarse_inv,
-              const std::vector<int64_t>& coarse_base, const AmgParams& prm, int max_m);
+              const std::vector<int64_t>& coarse_base, const AmgParams& prm, int max_m, const bk::Csr* fine_dev);
   // X = V(B) with zero initial guess; B, X: n0 x m row-major with leading dimensions ldb / ldx
   void vcycle(const double* B, int ldb, double* X, int ldx, int m);
   int nlevels() const { return (int)lv.size(); }
@@ -52,6 +53,7 @@ class AmgDevice {
     double *b = nullptr, *x = nullptr, *r = nullptr, *d = nullptr, *ad = nullptr;  // n x max_m work blocks
     int n = 0;
     double rho = 2.0;
+    bool own_A = true;
   };
   std::vector<Lvl> lv;
   bk::Chunks cch;              // chunks of the coarsest level (per subdomain)

@@ -103,97 +103,110 @@ constexpr int SPMV_TILE = 1792;  // nnz staged in LDS per workgroup (14 KB): 256
 constexpr int SPMV_ROWS = 256;   // rows per row block (one row per thread in the reduce phase)
 constexpr int SELL_LONG = 64;    // rows longer than this bypass the sliced layout
 
+// device-side construction of the sliced layout from the CSR arrays already in HBM
+__global__ void k_slice_width(const int* __restrict__ rowptr, int n, int ns, int* __restrict__ w) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  int m = 0;
+  const int r1 = (64 * s + 64 < n) ? 64 * s + 64 : n;
+  for (int i = 64 * s; i < r1; ++i) {
+    const int len = rowptr[i + 1] - rowptr[i];
+    if (len <= SELL_LONG && len > m) m = len;
+  }
+  w[s] = m;
+}
+__global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const double* __restrict__ val, int n, int ns,
+                                                   const int64_t* __restrict__ sl_ptr, int* __restrict__ sl_col,
+                                                   double* __restrict__ sl_val) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= ns) return;
+  const int l = threadIdx.x & 63;
+  const int i = 64 * s + l;
+  const int64_t base = sl_ptr[s];
+  const int w = (int)((sl_ptr[s + 1] - base) >> 6);
+  int a = 0, len = 0;
+  if (i < n) {
+    a = rowptr[i];
+    len = rowptr[i + 1] - a;
+  }
+  const bool use = (i < n) && len <= SELL_LONG;
+  const int padc = (i < n && len > 0) ? col[a] : 0;
+  for (int k = 0; k < w; ++k) {
+    const int64_t e = base + (int64_t)64 * k + l;
+    if (use && k < len) {
+      sl_col[e] = col[a + k];
+      sl_val[e] = val[a + k];
+    } else {
+      sl_col[e] = padc;
+      sl_val[e] = 0.0;
+    }
+  }
+}
+
+int spmv_kind();
+
 Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
   a.n = n;
   a.nnz = h_rowptr[n];
   a.rowptr = (int*)alloc(sizeof(int) * (size_t)(n + 1));
-  a.col = (int*)alloc(sizeof(int) * (size_t)a.nnz);
-  a.val = (double*)alloc(sizeof(double) * (size_t)a.nnz);
+  a.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)a.nnz));
+  a.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
   h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
   h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
-  // row blocks: as many consecutive rows as fit SPMV_TILE nnz and SPMV_ROWS rows; a row longer
-  // than the tile gets a block of its own (long-row path).
-  std::vector<int> blk;
-  blk.push_back(0);
-  int r = 0;
   int maxrow = 0;
-  while (r < n) {
-    int r1 = r;
-    int nz = 0;
-    while (r1 < n && (r1 - r) < SPMV_ROWS) {
-      int len = h_rowptr[r1 + 1] - h_rowptr[r1];
-      maxrow = std::max(maxrow, len);
-      if (nz + len > SPMV_TILE) break;
-      nz += len;
-      ++r1;
-    }
-    if (r1 == r) ++r1;  // single long row
-    blk.push_back(r1);
-    r = r1;
+  std::vector<int> longr;
+  for (int i = 0; i < n; ++i) {
+    const int len = h_rowptr[i + 1] - h_rowptr[i];
+    maxrow = std::max(maxrow, len);
+    if (len > SELL_LONG) longr.push_back(i);
   }
   a.max_row = maxrow;
-  a.nblk = (int)blk.size() - 1;
-  a.rowblk = (int*)alloc(sizeof(int) * blk.size());
-  h2d(a.rowblk, blk.data(), sizeof(int) * blk.size());
-  // 64-row slices, k-major, padded per slice (long rows excluded); built with host threads
+  if (spmv_kind() == 0) {
+    // row blocks of the LDS kernel: as many consecutive rows as fit SPMV_TILE nnz and SPMV_ROWS rows;
+    // a row longer than the tile gets a block of its own (long-row path)
+    std::vector<int> blk;
+    blk.push_back(0);
+    int r = 0;
+    while (r < n) {
+      int r1 = r;
+      int nz = 0;
+      while (r1 < n && (r1 - r) < SPMV_ROWS) {
+        const int len = h_rowptr[r1 + 1] - h_rowptr[r1];
+        if (nz + len > SPMV_TILE) break;
+        nz += len;
+        ++r1;
+      }
+      if (r1 == r) ++r1;  // single long row
+      blk.push_back(r1);
+      r = r1;
+    }
+    a.nblk = (int)blk.size() - 1;
+    a.rowblk = (int*)alloc(sizeof(int) * blk.size());
+    h2d(a.rowblk, blk.data(), sizeof(int) * blk.size());
+  }
+  // sliced layout, built on the device from the CSR arrays just uploaded
   {
     const int ns = (n + 63) / 64;
+    int* dw = (int*)alloc(sizeof(int) * std::max(1, ns));
+    if (ns > 0)
+      hipLaunchKernelGGL(k_slice_width, dim3(grid1d(ns, 256)), dim3(256), 0, g_stream, a.rowptr, n, ns, dw);
+    std::vector<int> w(std::max(1, ns));
+    d2h(w.data(), dw, sizeof(int) * ns);
+    dfree(dw);
     std::vector<int64_t> sp(ns + 1, 0);
-    std::vector<int> longr;
-    const int nth = (ns > 4096) ? std::max(1, std::min(16, (int)std::thread::hardware_concurrency())) : 1;
-    auto par = [&](const std::function<void(int, int)>& f) {
-      if (nth == 1) { f(0, ns); return; }
-      std::vector<std::thread> th;
-      for (int t = 0; t < nth; ++t)
-        th.emplace_back(f, (int)((int64_t)ns * t / nth), (int)((int64_t)ns * (t + 1) / nth));
-      for (auto& x : th) x.join();
-    };
-    par([&](int s0, int s1) {
-      for (int s = s0; s < s1; ++s) {
-        int w = 0;
-        for (int i = 64 * s; i < std::min(n, 64 * s + 64); ++i) {
-          const int len = h_rowptr[i + 1] - h_rowptr[i];
-          if (len <= SELL_LONG) w = std::max(w, len);
-        }
-        sp[s + 1] = (int64_t)64 * w;
-      }
-    });
-    for (int i = 0; i < n; ++i)
-      if (h_rowptr[i + 1] - h_rowptr[i] > SELL_LONG) longr.push_back(i);
-    for (int s = 0; s < ns; ++s) sp[s + 1] += sp[s];
-    std::vector<int> sc((size_t)std::max<int64_t>(1, sp[ns]));
-    std::vector<double> sv((size_t)std::max<int64_t>(1, sp[ns]));
-    par([&](int s0, int s1) {
-      for (int s = s0; s < s1; ++s) {
-        const int w = (int)((sp[s + 1] - sp[s]) / 64);
-        for (int li = 0; li < 64; ++li) {
-          const int i = 64 * s + li;
-          const int len = (i < n) ? h_rowptr[i + 1] - h_rowptr[i] : 0;
-          const bool use = (i < n) && len <= SELL_LONG;
-          const int padc = (i < n && len > 0) ? h_col[h_rowptr[i]] : 0;  // any valid column for the padding
-          for (int k = 0; k < w; ++k) {
-            const int64_t e = sp[s] + (int64_t)64 * k + li;
-            if (use && k < len) {
-              sc[e] = h_col[h_rowptr[i] + k];
-              sv[e] = h_val[h_rowptr[i] + k];
-            } else {
-              sc[e] = padc;
-              sv[e] = 0.0;
-            }
-          }
-        }
-      }
-    });
+    for (int s = 0; s < ns; ++s) sp[s + 1] = sp[s] + (int64_t)64 * w[s];
     a.nslice = ns;
     a.sl_nnz = sp[ns];
     a.sl_ptr = (int64_t*)alloc(sizeof(int64_t) * (ns + 1));
-    a.sl_col = (int*)alloc(sizeof(int) * sc.size());
-    a.sl_val = (double*)alloc(sizeof(double) * sv.size());
+    a.sl_col = (int*)alloc(sizeof(int) * (size_t)std::max<int64_t>(1, sp[ns]));
+    a.sl_val = (double*)alloc(sizeof(double) * (size_t)std::max<int64_t>(1, sp[ns]));
     h2d(a.sl_ptr, sp.data(), sizeof(int64_t) * (ns + 1));
-    h2d(a.sl_col, sc.data(), sizeof(int) * sc.size());
-    h2d(a.sl_val, sv.data(), sizeof(double) * sv.size());
+    if (ns > 0)
+      hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, g_stream, a.rowptr, a.col, a.val, n, ns,
+                         a.sl_ptr, a.sl_col, a.sl_val);
     a.nlong = (int)longr.size();
     a.long_rows = (int*)alloc(sizeof(int) * std::max<size_t>(1, longr.size()));
     h2d(a.long_rows, longr.data(), sizeof(int) * longr.size());
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(256) void k_spmv_long(const int* __restrict__ rows,
 }
 
 static int g_spmv_kind = -1;  // 0 = LDS row blocks, 1 = 64-row slices
-static int spmv_kind() {
+int spmv_kind() {
   if (g_spmv_kind < 0) {
     const char* e = getenv("GENEO_SPMV");
     g_spmv_kind = (e && std::string(e) == "lds") ? 0 : 1;
@@ -347,6 +360,7 @@ void spmv(const Csr& a, const double* x, double* y) {
     HIPCHK(hipEventRecord(e0, g_stream));
   }
   if (spmv_kind() == 0) {
+    if (!a.rowblk) throw std::runtime_error("spmv: matrix was uploaded without LDS row blocks (GENEO_SPMV=lds at upload)");
     hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
                        a.col, a.val, x, y);
   } else {

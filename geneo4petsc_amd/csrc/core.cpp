@@ -375,51 +375,46 @@ void PC::make_robin(Sub& s, HostCsr& out) const {
   }
 }
 
-static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
-                                const int* colmap /*nullable: L -> ext*/) {
+static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
+                              const int* colmap /*nullable: L -> ext*/) {
   const int ns = (int)mats.size();
-  const int n = suboff[ns];
-  std::vector<int> rp(n + 1, 0);
-  size_t nnz = 0;
-  for (auto* m : mats) nnz += m->val.size();
-  std::vector<int> col(nnz);
-  std::vector<double> val(nnz);
-  size_t pos = 0;
-  for (int s = 0; s < ns; ++s) {
+  HostCsr b;
+  b.n = suboff[ns];
+  b.rowptr.assign(b.n + 1, 0);
+  std::vector<size_t> nzoff(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) nzoff[s + 1] = nzoff[s] + mats[s]->val.size();
+  b.col.resize(nzoff[ns]);
+  b.val.resize(nzoff[ns]);
+  auto fill = [&](int s) {
     const HostCsr& m = *mats[s];
+    size_t pos = nzoff[s];
     for (int i = 0; i < m.n; ++i) {
       for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) {
         const int cl = suboff[s] + m.col[k];
-        col[pos] = colmap ? colmap[cl] : cl;
-        val[pos] = m.val[k];
+        b.col[pos] = colmap ? colmap[cl] : cl;
+        b.val[pos] = m.val[k];
         ++pos;
       }
-      rp[suboff[s] + i + 1] = (int)pos;
+      b.rowptr[suboff[s] + i + 1] = (int)pos;
     }
+  };
+  if (ns > 1 && nzoff[ns] > 1000000) {
+    std::vector<std::thread> th;
+    for (int s = 0; s < ns; ++s) th.emplace_back(fill, s);
+    for (auto& x : th) x.join();
+  } else {
+    for (int s = 0; s < ns; ++s) fill(s);
   }
-  return bk::csr_upload(n, rp.data(), col.data(), val.data());
+  return b;
+}
+static bk::Csr upload_host(const HostCsr& b) { return bk::csr_upload(b.n, b.rowptr.data(), b.col.data(), b.val.data()); }
+static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
+                                const int* colmap /*nullable: L -> ext*/) {
+  return upload_host(make_blockdiag(mats, suboff, colmap));
 }
 
 // AMG hierarchy of a block-diagonal matrix given by its per-subdomain blocks (host set-up)
-int PC::build_amg(const std::vector<const HostCsr*>& mats, int max_m, AmgDevice** out) {
-  const int ns = (int)mats.size();
-  HostCsr blk;
-  blk.n = nL;
-  blk.rowptr.assign(nL + 1, 0);
-  size_t nnz = 0;
-  for (auto* m : mats) nnz += m->val.size();
-  blk.col.reserve(nnz);
-  blk.val.reserve(nnz);
-  for (int s = 0; s < ns; ++s) {
-    const HostCsr& m = *mats[s];
-    for (int i = 0; i < m.n; ++i) {
-      for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) {
-        blk.col.push_back(suboff[s] + m.col[k]);
-        blk.val.push_back(m.val[k]);
-      }
-      blk.rowptr[suboff[s] + i + 1] = (int)blk.col.size();
-    }
-  }
+int PC::build_amg(const HostCsr& blk, int max_m, AmgDevice** out, const bk::Csr* fine_dev) {
   AmgParams ap;
   ap.coarse_size = opt.amg_coarse_size;
   ap.smooth_degree = opt.amg_smooth_degree;
@@ -429,10 +424,16 @@ int PC::build_amg(const std::vector<const HostCsr*>& mats, int max_m, AmgDevice*
   std::vector<double> cinv;
   std::vector<int64_t> cbase;
   try {
+    auto t0 = clk::now();
     amg_setup_host(blk, suboff, ap, levels, cinv, cbase);
+    auto t1 = clk::now();
     delete *out;
     *out = new AmgDevice();
-    (*out)->upload(levels, cinv, cbase, ap, max_m);
+    (*out)->upload(levels, cinv, cbase, ap, max_m, fine_dev);
+    bk::sync();
+    if (getenv("GENEO_DEBUG"))
+      fprintf(stderr, "[amg] host set-up %.3f s, upload %.3f s, %d levels\n", secs(t0, t1), secs(t1, clk::now()),
+              (int)levels.size());
   } catch (std::exception& e) {
     return fail(e.what());
   }
@@ -469,13 +470,15 @@ int PC::setup(const double* b_dev) {
     }
   }
   auto t1 = clk::now();
-  neuL = upload_blockdiag(neu, suboff, nullptr);
+  HostCsr h_neuL = make_blockdiag(neu, suboff, nullptr);
+  neuL = upload_host(h_neuL);
   {  // same matrix with ext-space columns for the MATIS MatMult (own copy: the sliced layout embeds the columns)
     std::vector<int> l2e(nL);
     bk::d2h(l2e.data(), d_l2e, sizeof(int) * nL);
     neuE = upload_blockdiag(neu, suboff, l2e.data());
   }
-  dirL = upload_blockdiag(lvl1, suboff, nullptr);
+  HostCsr h_dirL = make_blockdiag(lvl1, suboff, nullptr);
+  dirL = upload_host(h_dirL);
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {
     std::vector<double> D(std::max(1, nL));
@@ -514,12 +517,12 @@ int PC::setup(const double* b_dev) {
   {
     auto ta = clk::now();
     if (opt.dls1_pc == "amg")
-      if (int rc = build_amg(lvl1, 1, &amg1)) return rc;
+      if (int rc = build_amg(h_dirL, 1, &amg1, &dirL)) return rc;
     if (opt.lvl2 && opt.els2_pc == "amg") {
       const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
       const int want = nev_try + std::max(4, nev_try / 4);
       const int max_m = opt.eps_block > 0 ? opt.eps_block : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));
-      if (int rc = build_amg(neu, max_m, &amgN)) return rc;
+      if (int rc = build_amg(h_neuL, max_m, &amgN, &neuL)) return rc;
     }
     bk::sync();
     info.amgSetupTime = secs(ta, clk::now());

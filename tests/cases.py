@@ -49,9 +49,21 @@ def run_pc(lib, mesh, dec, argv, b, with_dir=True):
     return pc
 
 
-def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, xtol=1e-8, aptol=1e-9):
+def graph_case(size=400, level=2, nb=4, overlap=1, no_ground=True):
+    """BASELINE config 5 in small: tst/graph generator, node-range partition, irregular CSR."""
+    mesh = decomp.graph_mesh(size=size, level=level, no_ground=no_ground)
+    dec = decomp.decompose(mesh, nb, None, decomp.graph_node_partition(mesh, nb), False, overlap)
+    a = decomp.global_matrix(mesh)
+    return mesh, dec, a, decomp.rhs_default(a)
+
+
+def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, xtol=1e-8, aptol=1e-9, case=None,
+                        dim=3):
     """Full parity check of one configuration: integer outputs exact, floats within tolerance."""
-    mesh, dec, a, b = grid_case(n=n, parts=parts, overlap=overlap, **(gen or {}))
+    if case is not None:
+        mesh, dec, a, b = case
+    else:
+        mesh, dec, a, b = grid_case(n=n, dim=dim, parts=parts, overlap=overlap, **(gen or {}))
     pc = run_pc(lib, mesh, dec, argv, b, with_dir)
     orc = oracle_for(mesh, dec, argv, b)
     ksp, kw = ksp_args(argv)

@@ -33,6 +33,22 @@ def test_multilevel_amg_inner_preconditioner(lib):
     assert amg["dls1_iterations"] * 3 < jac["dls1_iterations"]
 
 
+def test_config0_laplacian_2d_two_subdomains_five_vectors(lib):
+    """BASELINE configs[0]: tst/laplacian 2-D stencil, 2 subdomains, 5 eigenvectors per subdomain."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "5", "-ksp_type", "gmres"] + TIGHT
+    its, info = cases.compare_with_oracle(lib, 40, (2, 1, 1), 1, argv, dim=2, gen=dict(kappa_max=2.0, interp="lin"))
+    assert info["dimE"] == 10
+
+
+@pytest.mark.parametrize("no_ground", [True, False])
+def test_config4_graph_irregular_csr(lib, no_ground):
+    """BASELINE configs[4] in small: tst/graph generator (with the ground node the matrix has one very
+    long row -> long-row SpMV kernel), node-range partition, 4 subdomains."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.3", "-geneo_cut", "6", "-ksp_type", "cg"] + TIGHT
+    cases.compare_with_oracle(lib, 0, None, 1, argv, case=cases.graph_case(size=400, level=2, nb=4, overlap=1,
+                                                                           no_ground=no_ground))
+
+
 def test_dirichlet_built_from_matis(lib):
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "cg"] + TIGHT
     cases.compare_with_oracle(lib, 10, (2, 2, 1), 1, argv, with_dir=False)
