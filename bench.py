@@ -256,6 +256,11 @@ def main():
             "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
             "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
             "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
+            "setup_breakdown_s": {"level1_upload_and_amg": info["lvl1SetupMinvTimeLoc"],
+                                  "eigensolve_lobpcg": info["lvl2SetupEigTimeLoc"],
+                                  "coarse_operator_E": info["lvl2SetupETimeLoc"]},
+            "solve_breakdown_s": {"local_solves": info["lvl1ApplyMinvTimeLoc"], "coarse_Zt": info["lvl2ApplyZtTimeLoc"],
+                                  "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
             "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs_rank / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": lib.GeneoSpmvKernelName().decode(), "launches_timed": int(nsamp.value),

@@ -170,10 +170,15 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     auto t_0 = tnow();
     const int n = L.A.n;
     std::vector<int> agg(n, -1), csub(nsub + 1, 0);
-    for (int s = 0; s < nsub; ++s) {
-      const int na = aggregate_block(L.A, L.suboff[s], L.suboff[s + 1], agg);
-      for (int i = L.suboff[s]; i < L.suboff[s + 1]; ++i) agg[i] += csub[s];
-      csub[s + 1] = csub[s] + na;
+    {  // the diagonal blocks are independent: one host thread per subdomain
+      std::vector<int> nagg(nsub, 0);
+      std::vector<std::thread> th;
+      for (int s = 0; s < nsub; ++s)
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(L.A, L.suboff[s], L.suboff[s + 1], agg); });
+      for (auto& x : th) x.join();
+      for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
+      for (int s = 0; s < nsub; ++s)
+        for (int i = L.suboff[s]; i < L.suboff[s + 1]; ++i) agg[i] += csub[s];
     }
     const int nc = csub[nsub];
     if (nc >= n) break;  // no coarsening possible

@@ -414,32 +414,21 @@ static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const s
 }
 
 // AMG hierarchy of a block-diagonal matrix given by its per-subdomain blocks (host set-up)
-int PC::build_amg(const HostCsr& blk, int max_m, AmgDevice** out, const bk::Csr* fine_dev) {
+struct AmgHostResult {
+  std::vector<AmgLevelHost> levels;
+  std::vector<double> cinv;
+  std::vector<int64_t> cbase;
+  std::string err;
+  double secs = 0.0;
+};
+
+static AmgParams amg_params(const Options& opt) {
   AmgParams ap;
   ap.coarse_size = opt.amg_coarse_size;
   ap.smooth_degree = opt.amg_smooth_degree;
   ap.smooth_ratio = opt.amg_smooth_ratio;
   ap.max_levels = opt.amg_max_levels;
-  std::vector<AmgLevelHost> levels;
-  std::vector<double> cinv;
-  std::vector<int64_t> cbase;
-  try {
-    auto t0 = clk::now();
-    amg_setup_host(blk, suboff, ap, levels, cinv, cbase);
-    auto t1 = clk::now();
-    delete *out;
-    *out = new AmgDevice();
-    (*out)->upload(levels, cinv, cbase, ap, max_m, fine_dev);
-    bk::sync();
-    if (getenv("GENEO_DEBUG"))
-      fprintf(stderr, "[amg] host set-up %.3f s, upload %.3f s, %d levels\n", secs(t0, t1), secs(t1, clk::now()),
-              (int)levels.size());
-  } catch (std::exception& e) {
-    return fail(e.what());
-  }
-  info.amg_levels = (*out)->nlevels();
-  info.amg_operator_complexity = (*out)->operator_complexity();
-  return 0;
+  return ap;
 }
 
 // ------------------------------------------------------------------------------------ setup
@@ -515,17 +504,55 @@ int PC::setup(const double* b_dev) {
     bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
   }
   {
+    // Inner AMG hierarchies: A_Dir (local solves) and A_Neu (LOBPCG).  The host set-ups are independent
+    // and device-free: they run concurrently; uploads follow on the stream.
     auto ta = clk::now();
-    if (opt.dls1_pc == "amg")
-      if (int rc = build_amg(h_dirL, 1, &amg1, &dirL)) return rc;
-    if (opt.lvl2 && opt.els2_pc == "amg") {
-      const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
-      const int want = nev_try + std::max(4, nev_try / 4);
-      const int max_m = opt.eps_block > 0 ? opt.eps_block : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));
-      if (int rc = build_amg(h_neuL, max_m, &amgN, &neuL)) return rc;
+    const bool want1 = (opt.dls1_pc == "amg");
+    const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
+    const AmgParams ap = amg_params(opt);
+    AmgHostResult r1, rN;
+    auto host = [&](const HostCsr* blk, AmgHostResult* r) {
+      auto t0 = clk::now();
+      try {
+        amg_setup_host(*blk, suboff, ap, r->levels, r->cinv, r->cbase);
+      } catch (std::exception& e) {
+        r->err = e.what();
+      }
+      r->secs = secs(t0, clk::now());
+    };
+    std::thread th1, thN;
+    if (want1) th1 = std::thread(host, &h_dirL, &r1);
+    if (wantN) thN = std::thread(host, &h_neuL, &rN);
+    if (th1.joinable()) th1.join();
+    if (thN.joinable()) thN.join();
+    if (!r1.err.empty()) return fail(r1.err);
+    if (!rN.err.empty()) return fail(rN.err);
+    try {
+      if (want1) {
+        amg1 = new AmgDevice();
+        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, 1, &dirL);
+        info.amg_levels = amg1->nlevels();
+        info.amg_operator_complexity = amg1->operator_complexity();
+      }
+      if (wantN) {
+        const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
+        const int want = nev_try + std::max(4, nev_try / 4);
+        const int max_m = opt.eps_block > 0 ? opt.eps_block : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));
+        amgN = new AmgDevice();
+        amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, max_m, &neuL);
+        if (!want1) {
+          info.amg_levels = amgN->nlevels();
+          info.amg_operator_complexity = amgN->operator_complexity();
+        }
+      }
+    } catch (std::exception& e) {
+      return fail(e.what());
     }
     bk::sync();
     info.amgSetupTime = secs(ta, clk::now());
+    if (getenv("GENEO_DEBUG"))
+      fprintf(stderr, "[amg] host set-ups %.3f / %.3f s (concurrent), total with uploads %.3f s\n", r1.secs, rN.secs,
+              info.amgSetupTime);
   }
   bk::sync();
   info.lvl1SetupMinvTimeLoc = secs(t1, clk::now());

@@ -148,7 +148,6 @@ class PC {
   double cheb_lmax = 2.0;
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
-  int build_amg(const HostCsr& blk, int max_m, AmgDevice** out, const bk::Csr* fine_dev);
 
   int fail(const std::string& msg);
   int build_layout();
