@@ -49,6 +49,7 @@ SYMBOLS = {
     "PCGenEOSetOption": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "PCGenEOGetName": (C.c_char_p, [C.c_void_p]),
     "PCGenEOGetError": (C.c_char_p, [C.c_void_p]),
+    "PCGenEOGetOptionsString": (C.c_char_p, [C.c_void_p]),
     "usageGenEO_c": (C.c_char_p, []),
     "PCSetOperators_GenEO": (C.c_int, [C.c_void_p, C.POINTER(GeneoMatIS)]),
     "PCGenEOSetup": (C.c_int, [C.c_void_p, C.POINTER(GeneoCsr), GeneoIS, C.POINTER(GeneoIS)]),

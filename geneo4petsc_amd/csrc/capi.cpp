@@ -1,4 +1,5 @@
 // extern "C" entry points of libgeneopc (declared in include/geneo_c.h).
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -9,7 +10,7 @@
 
 struct _p_GeneoPC {
   geneo::PC* ctx = nullptr;   // pc->data in PETSc (src/geneo.cpp:2645)
-  std::string name, err;
+  std::string name, err, optstr;
   // PCSetOperators_GenEO copy (the MATIS A of the one-subdomain-per-rank model)
   bool has_ops = false;
   int nbDOF = 0, nbDOFLoc = 0;
@@ -114,6 +115,21 @@ PetscErrorCode PCSetFromOptions_GenEO(PC pc, int argc, const char* const* argv) 
 }
 
 const char* PCGenEOGetName(PC pc) { return pc ? pc->name.c_str() : ""; }
+const char* PCGenEOGetOptionsString(PC pc) {
+  if (!pc || !pc->ctx) return "";
+  const geneo::Options& o = pc->ctx->opt;
+  char buf[1024];
+  snprintf(buf, sizeof(buf),
+           "lvl1ASM=%d;lvl1RAS=%d;lvl1SRAS=%d;lvl1ORAS=%d;lvl2=%d;hybrid=%d;effHybrid=%d;optim=%.17g;tau=%.17g;"
+           "gamma=%.17g;cst=%d;cut=%d;noSyl=%d;offload=%d;eps_tol=%.17g;dls1_rtol=%.17g;dls1_pc=%s;els2_pc=%s;"
+           "ksp_type=%s;ksp_rtol=%.17g;ksp_atol=%.17g;ksp_max_it=%d;ksp_restart=%d",
+           (int)o.lvl1ASM, (int)o.lvl1RAS, (int)o.lvl1SRAS, (int)o.lvl1ORAS, o.lvl2, (int)o.hybrid, (int)o.effHybrid,
+           o.optim, o.tau, o.gamma, (int)o.cst, o.cut, (int)o.noSyl, (int)o.offload, o.eps_tol, o.dls1_rtol,
+           o.dls1_pc.c_str(), o.els2_pc.c_str(), o.ksp_type.c_str(), o.ksp_rtol, o.ksp_atol, o.ksp_max_it,
+           o.ksp_restart);
+  pc->optstr = buf;
+  return pc->optstr.c_str();
+}
 const char* PCGenEOGetError(PC pc) { return pc ? pc->err.c_str() : g_global_err.c_str(); }
 
 const char* usageGenEO_c(void) {

@@ -96,6 +96,19 @@ class GenEOPC:
     def name(self):
         return self.lib.PCGenEOGetName(self.h).decode()
 
+    def options(self):
+        """The parsed options (the public parameter fields of the reference's geneoContext)."""
+        out = {}
+        for kv in self.lib.PCGenEOGetOptionsString(self.h).decode().split(";"):
+            k, _, v = kv.partition("=")
+            if k in ("dls1_pc", "els2_pc", "ksp_type"):
+                out[k] = v
+            elif "." in v or "e" in v or "inf" in v:
+                out[k] = float(v)
+            else:
+                out[k] = int(v)
+        return out
+
     def usage(self):
         return self.lib.usageGenEO_c().decode()
 

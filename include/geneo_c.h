@@ -75,6 +75,9 @@ PetscErrorCode PCGenEOSetOption(PC pc, const char* key, const char* value);
 /* buildGenEOName, src/geneo.cpp:2245-2268 ("geneo1ASM", "geneo1HASM", ...) */
 const char* PCGenEOGetName(PC pc);
 const char* PCGenEOGetError(PC pc);
+/* the parsed options as "key=value;..." (what the driver reads from the public geneoContext fields,
+ * src/geneo4PETSc.cpp:928-989) */
+const char* PCGenEOGetOptionsString(PC pc);
 /* usageGenEO, src/geneo.cpp:2274-2327 */
 const char* usageGenEO_c(void);
 

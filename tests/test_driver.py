@@ -1,0 +1,52 @@
+"""The CLI driver's INFO:/TIME: lines (reference shapes, driver:898-1231) -- host logic only (hostsim)."""
+import io
+import os
+import re
+
+import numpy as np
+
+import dummy_cases as dc
+import hostsim_util as hu
+from geneo4petsc_amd import driver
+
+
+def test_info_lines_match_the_dummy_goldens(tmp_path):
+    """Lines 0-1 and the solve line are byte-identical to tst/dummy/*.ref; line 2 keeps the reference's
+    token layout (tst/plot.py:74-95 parses it positionally) with this build's solver names."""
+    d = dc.load()
+    rec = [r for r in dc.geneo_refs() if r["file"] == "tridiag-pc=geneoASMH1-metis=nodal-opt=overlap1.ref"][0]
+    inp = tmp_path / "tridiag.inp"
+    inp.write_text(d["inputs"]["tridiag.inp"])
+    ep, npart = dc.partition_for(rec)
+    pf = tmp_path / "part.txt"
+    pf.write_text("\n".join(str(v) for v in npart))
+    buf = io.StringIO()
+    lines, x = driver.run(["--inpFileA", str(inp), "--inpEps", "1.", "--np", "2", "--partFile", str(pf), "--metisNodal",
+                           "--addOverlap", "1", "--shortRes", "-geneo_lvl", "ASM,H1", "-geneo_cut", "10",
+                           "-ksp_rtol", "1e-12", "-ksp_atol", "1e-12"], lib=hu.hostsim_lib(), out=buf)
+    assert lines[0] == rec["info"][0]
+    assert lines[1] == rec["info"][1]
+    assert lines[2].startswith("INFO: geneo1HASM pc, L1 ") and ", tau 0.10, L2 " in lines[2]
+    assert lines[3] == rec["info"][3] == "INFO: solve - converged"
+    np.testing.assert_allclose(x, rec["x"], rtol=1e-5)
+
+
+def test_full_lines_parse_like_plot_py():
+    buf = io.StringIO()
+    lines, _ = driver.run(["--inpLibA", "laplacian#--size#8#--dim#3", "--np", "8", "--parts", "2,2,2", "--metisNodal",
+                           "--addOverlap", "1", "--timing", "-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "4",
+                           "-ksp_type", "cg"], lib=hu.hostsim_lib(), out=buf)
+    info = [l for l in lines if l.startswith("INFO:")]
+    # the token positions tst/plot.py relies on
+    l0 = info[0].split()
+    assert l0[l0.index("DOFs") + 1] == "512," and l0[l0.index("metis") + 1] == "nodal"
+    l2 = info[2].split()
+    assert l2[l2.index("pc,") - 1] == "geneo1ASM" and l2[l2.index("tau") + 1] == "0.20,"
+    l3 = info[3].split()
+    assert int(l3[l3.index("real") + 2]) == 32 or int(l3[l3.index("real") + 2]) > 0
+    l4 = info[4].split()
+    assert int(l4[5].replace(",", "")) > 0                      # iteration count position (plot.py:98)
+    t = [l for l in lines if l.startswith("TIME:")][0].split()
+    for pos in (3, 8, 12, 17, 21, 24):                          # plot.py:100-105
+        float(t[pos].replace(",", ""))
+    assert re.match(r"^      L1       setup: Minv \d+\.\d{5} s$", [l for l in lines if "L1       setup" in l][0])
