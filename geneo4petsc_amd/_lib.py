@@ -74,6 +74,8 @@ SYMBOLS = {
     "PCGenEOGetCandidates": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, C.c_int]),
     "PCGenEOGetE": (C.c_int, [C.c_void_p, c_dbl_p, C.c_int]),
     "PCGenEOGetLocalDims": (C.c_int, [C.c_void_p, c_int_p, C.c_int]),
+    "PCGenEOGetLocalParams": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p, C.c_int]),
+    "PCGenEOSetIntersect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
     "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),

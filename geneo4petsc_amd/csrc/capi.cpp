@@ -184,7 +184,6 @@ PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int n, const int* map, const 
 }
 
 PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS mults, const GeneoIS* inters) {
-  (void)inters;  // only its emptiness is used, and only by GenEO-2 (src/geneo.cpp:1139-1148)
   if (!pc || !pc->ctx) return 1;
   if (!pc->has_ops) return pcfail(pc, "GenEO preconditioner: PCSetOperators_GenEO must be called first");
   if (mults.n != pc->nbDOFLoc) return pcfail(pc, "Mismatch in dof mult size and local size");
@@ -192,7 +191,21 @@ PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS mults, con
   if (c->N == 0) c->N = pc->nbDOF;
   if (c->nsub_global == 0) c->nsub_global = c->size;
   GeneoCsr a{pc->nbDOFLoc, pc->rowptr.data(), pc->col.data(), pc->val.data()};
-  return PCGenEOAddSubdomain(pc, c->rank, pc->nbDOFLoc, pc->map.data(), mults.idx, &a, pcADirLoc);
+  if (PetscErrorCode rc = PCGenEOAddSubdomain(pc, c->rank, pc->nbDOFLoc, pc->map.data(), mults.idx, &a, pcADirLoc))
+    return rc;
+  if (inters) {  // only the emptiness of each list is used, and only by GenEO-2 (src/geneo.cpp:1139-1148)
+    std::vector<int> flags(c->nsub_global);
+    for (int q = 0; q < c->nsub_global; ++q) flags[q] = inters[q].n > 0;
+    return PCGenEOSetIntersect(pc, c->rank, c->nsub_global, flags.data());
+  }
+  return 0;
+}
+
+PetscErrorCode PCGenEOSetIntersect(PC pc, int gid, int nb, const int* nonempty) {
+  if (!pc || !pc->ctx) return 1;
+  GUARD_BEGIN
+  return propagate(pc, pc->ctx->set_intersect(gid, nb, nonempty));
+  GUARD_END(pc)
 }
 
 PetscErrorCode initGenEOPC_c(PC pc, unsigned int nbDOF, unsigned int nbDOFLoc, const int* map, const GeneoCsr* A,
@@ -325,6 +338,16 @@ int PCGenEOGetE(PC pc, double* e, int cap) {
   if (!pc || !pc->ctx) return -1;
   copy_out(pc->ctx->E, e, cap);
   return pc->ctx->info.dimE;
+}
+int PCGenEOGetLocalParams(PC pc, double* tau, double* gamma, int cap) {
+  if (!pc || !pc->ctx) return -1;
+  const auto& t = pc->ctx->tauLoc;
+  const auto& g = pc->ctx->gammaLoc;
+  for (int i = 0; i < (int)t.size() && i < cap; ++i) {
+    if (tau) tau[i] = t[i];
+    if (gamma) gamma[i] = i < (int)g.size() ? g[i] : -1.0;
+  }
+  return (int)t.size();
 }
 int PCGenEOGetLocalDims(PC pc, int* k, int cap) {
   if (!pc || !pc->ctx) return -1;

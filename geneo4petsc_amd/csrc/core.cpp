@@ -204,6 +204,16 @@ int PC::add_subdomain(int gid, int n, const int* l2g, const int* mult, const int
   return 0;
 }
 
+int PC::set_intersect(int gid, int nb, const int* nonempty) {
+  if (nb < 0 || (nb > 0 && !nonempty)) return fail("GenEO preconditioner: bad intersection flags");
+  for (auto& s : subs)
+    if (s.gid == gid) {
+      s.intersect.assign(nonempty, nonempty + nb);
+      return 0;
+    }
+  return fail("GenEO preconditioner: intersection flags for an unknown subdomain");
+}
+
 // ------------------------------------------------------------------------------------ layout
 int PC::build_layout() {
   const int ns = (int)subs.size();
@@ -437,7 +447,8 @@ int PC::setup(const double* b_dev) {
   if (is_setup) free_all();
   std::string err = validate_options(opt);
   if (!err.empty()) return fail(err);
-  if (opt.lvl2 == 2) return fail("GenEO-2 (lvl2 = 2 / SORAS,2) is not built yet on the MI355X path");
+  if (opt.lvl2 == 2 && !opt.lvl1ORAS)
+    return fail("GenEO-2 needs the Robin matrix: use -geneo_lvl ORAS,2 or SORAS,2 (geneo.cpp:1283 takes pcARobLoc)");
   if (N <= 0) return fail("GenEO preconditioner: empty problem");
   if (int rc = build_layout()) return rc;
   if (int rc = ensure_dirichlet()) return rc;
@@ -500,6 +511,20 @@ int PC::setup(const double* b_dev) {
       }
     }
     cheb_lmax = lmax > 0 ? lmax : 2.0;
+    if (opt.lvl2 == 2) {  // same bound for the level-1 (Robin) matrix: Chebyshev fallback of the gamma eigenproblem
+      std::vector<double> d1(std::max(1, nL));
+      bk::d2h(d1.data(), d_dinv1, sizeof(double) * nL);
+      double l1 = 0.0;
+      for (int s = 0; s < ns; ++s) {
+        const HostCsr& m = *lvl1[s];
+        for (int i = 0; i < m.n; ++i) {
+          double row = 0.0;
+          for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
+          l1 = std::max(l1, row * d1[suboff[s] + i]);
+        }
+      }
+      cheb_lmax1 = l1 > 0 ? l1 : 2.0;
+    }
     for (int i = 0; i < nL; ++i) dg[i] = 1.0 / dg[i];
     bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
   }
@@ -530,14 +555,13 @@ int PC::setup(const double* b_dev) {
     try {
       if (want1) {
         amg1 = new AmgDevice();
-        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, 1, &dirL);
+        // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
+        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_targets(nullptr) : 1, &dirL);
         info.amg_levels = amg1->nlevels();
         info.amg_operator_complexity = amg1->operator_complexity();
       }
       if (wantN) {
-        const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
-        const int want = nev_try + std::max(4, nev_try / 4);
-        const int max_m = opt.eps_block > 0 ? opt.eps_block : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));
+        const int max_m = eig_targets(nullptr);
         amgN = new AmgDevice();
         amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, max_m, &neuL);
         if (!want1) {
@@ -754,6 +778,8 @@ int PC::setup_level2(const double* b_dev) {
   auto t0 = clk::now();
   eigvals.assign(ns, {});
   candidates.assign(ns, {});
+  local_tau();
+  if (opt.lvl2 != 2) tauLoc.assign(ns, opt.tau);  // GenEO-1 uses the global tau (geneo.cpp:1271)
   int nmax = 0;
   for (auto& s : subs) nmax = std::max(nmax, (int)s.l2g.size());
   int rc = 0;
@@ -785,22 +811,36 @@ int PC::setup_level2(const double* b_dev) {
 // full pencil; solved with the same rank-revealing Rayleigh-Ritz routine LOBPCG uses.
 int PC::eigen_dense_host() {
   const int ns = (int)subs.size();
-  const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
+  const bool g2 = (opt.lvl2 == 2);
+  int nev_try = 0;
+  eig_targets(&nev_try);
+  if (g2)
+    if (int rc = local_gamma()) return rc;
   std::vector<std::vector<std::vector<double>>> vecs(ns);
+  auto densify = [](const HostCsr& a, const std::vector<int>* mult, std::vector<double>& G) {
+    const int n = a.n;
+    G.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int c = a.col[k];
+        G[(size_t)i * n + c] += mult ? a.val[k] / ((double)(*mult)[i] * (double)(*mult)[c]) : a.val[k];
+      }
+  };
   for (int s = 0; s < ns; ++s) {
     Sub& sd = subs[s];
     const int n = (int)sd.l2g.size();
-    std::vector<double> GA((size_t)n * n, 0.0), GB((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i)
-      for (int k = sd.a_neu.rowptr[i]; k < sd.a_neu.rowptr[i + 1]; ++k) GA[(size_t)i * n + sd.a_neu.col[k]] += sd.a_neu.val[k];
-    for (int i = 0; i < n; ++i)
-      for (int k = sd.a_dir.rowptr[i]; k < sd.a_dir.rowptr[i + 1]; ++k) {
-        const int c = sd.a_dir.col[k];
-        GB[(size_t)i * n + c] += sd.a_dir.val[k] / ((double)sd.mult[i] * (double)sd.mult[c]);
-      }
+    std::vector<double> GA, GW, GR;
+    densify(sd.a_neu, nullptr, GA);
+    densify(sd.a_dir, &sd.mult, GW);           // B_w = D A_Dir D
+    if (g2) {
+      HostCsr rob;
+      make_robin(sd, rob);
+      densify(rob, nullptr, GR);
+    }
+    const std::vector<double>& GB = g2 ? GR : GW;
     std::vector<double> th, C;
-    const int r = dense::gen_eig_rr(GA, GB, n, 0, 1e-13, th, C);
-    const int nev = std::min(std::min(nev_try, n), r);
+    int r = dense::gen_eig_rr(GA, GB, n, 0, 1e-13, th, C);
+    int nev = std::min(std::min(nev_try, n), r);
     // TARGET_MAGNITUDE around 0 (geneo.cpp:638-640): smallest |theta| first
     std::vector<int> ord(r);
     std::iota(ord.begin(), ord.end(), 0);
@@ -808,7 +848,7 @@ int PC::eigen_dense_host() {
     for (int j = 0; j < nev; ++j) {
       const int c = ord[j];
       candidates[s].push_back(th[c]);
-      if (th[c] > opt.tau) continue;  // geneo.cpp:713
+      if (th[c] > tauLoc[s]) continue;  // geneo.cpp:713
       eigvals[s].push_back(th[c]);
       std::vector<double> v(n);
       for (int i = 0; i < n; ++i) v[i] = C[(size_t)i * r + c];
@@ -822,6 +862,22 @@ int PC::eigen_dense_host() {
         eigvals[s].push_back(0.0);
         vecs[s].push_back(std::vector<double>(n, 1.0));
         info.nicolaidesLoc++;
+      }
+    }
+    if (g2) {  // gamma problem (geneo.cpp:1299): largest eigenvalues of B_w v = lambda A_Rob v, kept when >= gamma_loc
+      r = dense::gen_eig_rr(GW, GR, n, 0, 1e-13, th, C);
+      nev = std::min(std::min(nev_try, n), r);
+      ord.resize(r);
+      std::iota(ord.begin(), ord.end(), 0);
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(th[a]) > std::fabs(th[b]); });
+      for (int j = 0; j < nev; ++j) {
+        const int c = ord[j];
+        candidates[s].push_back(th[c]);
+        if (th[c] < gammaLoc[s]) continue;  // geneo.cpp:717
+        eigvals[s].push_back(th[c]);
+        std::vector<double> v(n);
+        for (int i = 0; i < n; ++i) v[i] = C[(size_t)i * r + c];
+        vecs[s].push_back(std::move(v));
       }
     }
     if (vecs[s].empty()) {  // geneo.cpp:1305-1314
@@ -851,22 +907,17 @@ int PC::eigen_dense_host() {
   return 0;
 }
 
-// LOBPCG on A_Neu v = lambda (D A_Dir D) v for all local subdomains in lock step.
+// LOBPCG on a pencil A v = lambda B v (lowest eigenvalues) for all local subdomains in lock step.
 // Basis S = [X | P | W] (n_L x 3m row-major).  Per iteration and subdomain:
-//   W = T (A X - B X Lambda)              T = Chebyshev(degree, Jacobi) on A_Neu     (SpMM)
+//   W = T (A X - B X Lambda)              T = AMG V-cycle of A, or Chebyshev(degree, Jacobi) on A   (SpMM)
 //   G_A = S^T (A S), G_B = S^T (B S)      FP64-MFMA Gram kernels
 //   rank-revealing Rayleigh-Ritz on host  (3m x 3m)
 //   [X P] <- S C, same for A S, B S       FP64-MFMA block update kernels
-int PC::eigen_lobpcg() {
+// On return lam[s*m+j] holds the Ritz values (1e300 = fewer independent directions than m) and Xc
+// (n_L x m, row-major, device) the B-orthonormal Ritz vectors.
+int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc) {
   const int ns = (int)subs.size();
-  const int nev_try = opt.cut > 0 ? opt.cut : opt.eps_nev;
-  int m = opt.eps_block;
-  if (m <= 0) {
-    const int want = nev_try + std::max(4, nev_try / 4);
-    m = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
-  }
-  if (m != 16 && m != 32 && m != 64) return fail("GenEO: -els2_eps_block must be 16, 32 or 64");
-  if (nev_try > m) return fail("GenEO: -geneo_cut / -els2_eps_nev larger than the LOBPCG block (max 64)");
+  const int nev_try = P.nev_try;
   const int p3 = 3 * m;
   const size_t blk = (size_t)nL * p3;
   auto dv = [](size_t n) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, n)); };
@@ -877,21 +928,13 @@ int PC::eigen_lobpcg() {
   std::vector<double*> owned_bufs = {S, AS, BS, T, AT, BT, cr, cd, cad, dGA, dGB, dC, dlam, dnr, dna, dnb};
   auto cleanup = [&]() { for (double* p : owned_bufs) bk::dfree(p); };
 
-  auto applyA = [&](const double* X, double* Y) { bk::spmm_strided(neuL, X, p3, Y, p3, m, nullptr, nullptr); info.eig_spmm++; };
-  // B = D A_Dir D always uses the true Dirichlet matrix: rebuild if level 1 holds the Robin one
-  bk::Csr dirB = dirL;
-  bool own_dirB = false;
-  if (opt.lvl1ORAS) {
-    std::vector<const HostCsr*> dm(ns);
-    for (int s = 0; s < ns; ++s) dm[s] = &subs[s].a_dir;
-    dirB = upload_blockdiag(dm, suboff, nullptr);
-    own_dirB = true;
-  }
-  auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(dirB, X, p3, Y, p3, m, d_D, d_D); info.eig_spmm++; };
+  auto applyA = [&](const double* X, double* Y) { bk::spmm_strided(*P.A, X, p3, Y, p3, m, P.As, P.As); info.eig_spmm++; };
+  auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(*P.B, X, p3, Y, p3, m, P.Bs, P.Bs); info.eig_spmm++; };
 
   std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
-  std::vector<double> lam((size_t)ns * m, 0.0), nr((size_t)ns * m), na((size_t)ns * m), nb((size_t)ns * m);
+  std::vector<double> nr((size_t)ns * m), na((size_t)ns * m), nb((size_t)ns * m);
   std::vector<std::vector<double>> res(ns, std::vector<double>(m, 1.0));
+  lam.assign((size_t)ns * m, 0.0);
 
   // ---- start block + Rayleigh-Ritz on X alone
   bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed);
@@ -963,7 +1006,7 @@ int PC::eigen_lobpcg() {
   bk::block_axpby(BS + m, p3, 0.0, BS + m, p3, 0.0, nL, m);
 
   const double tol = opt.eps_tol;
-  const double lmax = cheb_lmax * 1.05, lmin = lmax / std::max(1.5, opt.cheb_ratio);
+  const double lmax = P.lmax * 1.05, lmin = lmax / std::max(1.5, opt.cheb_ratio);
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
   int it = 0;
   bool all_done = false;
@@ -1003,14 +1046,13 @@ int PC::eigen_lobpcg() {
       else all_done = false;
     }
     if (getenv("GENEO_DEBUG")) {
-      fprintf(stderr, "[lobpcg] it %d maxres:", it);
+      fprintf(stderr, "[lobpcg %s] it %d maxres:", P.label, it);
       for (int s = 0; s < ns; ++s) {
         double mx = 0.0;
         for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
         fprintf(stderr, " %.2e", mx);
       }
-      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1],
-              (opt.els2_pc == "amg" && amgN) ? "amg" : "cheb");
+      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
     }
     if (all_done || it == opt.eps_max_it) break;
     bool any_locked = false;
@@ -1025,21 +1067,21 @@ int PC::eigen_lobpcg() {
       bk::block_colscale(ch, AS + m, p3, m, dmask);
       bk::block_colscale(ch, BS + m, p3, m, dmask);
     }
-    if (opt.els2_pc == "amg" && amgN) {
-      // W = T r : one smoothed-aggregation V-cycle of A_Neu on the whole block (~ shift-invert at sigma = 0)
-      amgN->vcycle(cr, m, W, p3, m);
+    if (P.amg) {
+      // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
+      P.amg->vcycle(cr, m, W, p3, m);
       info.eig_spmm += 3;
     } else {
-      // W = T r : Chebyshev iteration on A_Neu z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
+      // W = T r : Chebyshev iteration on A z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
       double rho = 1.0 / sigma;
-      bk::block_rowscale(cd, m, cr, m, d_dinvN, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
-      bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                       // z = d
+      bk::block_rowscale(cd, m, cr, m, P.dinv, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
+      bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                      // z = d
       for (int k = 1; k < opt.cheb_degree; ++k) {
-        bk::spmm_strided(neuL, cd, m, cad, m, m, nullptr, nullptr);         // A d
+        bk::spmm_strided(*P.A, cd, m, cad, m, m, P.As, P.As);              // A d
         info.eig_spmm++;
         const double rho_new = 1.0 / (2.0 * sigma - rho);
         // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
-        bk::cheb_update(cr, cad, cd, W, p3, d_dinvN, 2.0 * rho_new / delta, rho_new * rho, nL, m);
+        bk::cheb_update(cr, cad, cd, W, p3, P.dinv, 2.0 * rho_new / delta, rho_new * rho, nL, m);
         rho = rho_new;
       }
     }
@@ -1047,73 +1089,234 @@ int PC::eigen_lobpcg() {
     applyB(W, BS + 2 * m);
     rayleigh_ritz(p3, m, 2 * m, true);
   }
-  info.eig_iterations = it;
+  info.eig_iterations += it;
+  if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
+  bk::sync();
+  cleanup();
   if (!all_done) {
     // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).
-    cleanup();
-    if (own_dirB) bk::csr_free(dirB);
     std::ostringstream msg;
-    msg << "GenEO preconditioner: els2-tau KO (EPS_DIVERGED_ITS after " << it << " LOBPCG iterations)";
+    msg << "GenEO preconditioner: els2-" << P.label << " KO (EPS_DIVERGED_ITS after " << it << " LOBPCG iterations)";
     return fail(msg.str());
   }
+  return 0;
+}
+
+// Number of eigenpairs asked per problem (geneo.cpp:855-879 without the inertia count: the block
+// always carries the -geneo_cut cap, the threshold filter removes the rest) and the LOBPCG block.
+int PC::eig_targets(int* nev_try) const {
+  int cut = opt.cut;
+  if (opt.lvl2 == 2 && cut >= 2) cut /= 2;  // GenEO-2 has two eigenproblems, geneo.cpp:1275
+  int nev = cut > 0 ? cut : opt.eps_nev;
+  if (opt.noSyl && cut > 0) nev = std::min(opt.eps_nev, cut);  // geneo.cpp:855,:871-879
+  if (opt.noSyl && cut <= 0) nev = opt.eps_nev;
+  if (nev_try) *nev_try = nev;
+  if (opt.eps_block > 0) return opt.eps_block;
+  const int want = nev + std::max(4, nev / 4);
+  return want <= 16 ? 16 : (want <= 32 ? 32 : 64);
+}
+
+// getLocalGenEOTau, geneo.cpp:1097-1118
+void PC::local_tau() {
+  const int ns = (int)subs.size();
+  tauLoc.assign(ns, opt.tau);
+  if (opt.cst) return;
+  for (int s = 0; s < ns; ++s) {
+    int k = 0;
+    for (int v : subs[s].mult) k = std::max(k, v);
+    double t = k * opt.tau;
+    if (t >= 1.0) t = 0.9;
+    tauLoc[s] = t;
+  }
+}
+
+// getLocalGenEOGamma, geneo.cpp:1120-1232 -- follows the code, including the test at :1143-1145 that
+// stores 0 where two subdomains DO intersect.
+int PC::local_gamma() {
+  const int ns = (int)subs.size(), Pn = nsub_global;
+  gammaLoc.assign(ns, opt.gamma);
+  if (opt.cst) return 0;
+  // emptiness flags of intersectLoc: supplied (PCGenEOSetIntersect) or, on one rank, derived from the maps
+  std::vector<double> c((size_t)Pn * Pn, 0.0);
+  bool have_all = true;
+  for (auto& s : subs) have_all = have_all && (int)s.intersect.size() == Pn;
+  if (!have_all) {
+    if (size > 1) return fail("GenEO-2: intersection flags are required on several ranks (PCGenEOSetIntersect), or use -geneo_cst");
+    std::vector<std::vector<int>> owners(N);
+    for (int s = 0; s < ns; ++s)
+      for (int g : subs[s].l2g) owners[g].push_back(s);
+    for (auto& s : subs) s.intersect.assign(Pn, 0);
+    for (auto& o : owners)
+      for (int a : o)
+        for (int b : o)
+          if (a != b) subs[a].intersect[subs[b].gid] = 1;
+  }
+  for (auto& s : subs)
+    for (int q = 0; q < Pn; ++q) c[(size_t)s.gid * Pn + q] = (q == s.gid) ? 1.0 : (s.intersect[q] ? 0.0 : 1.0);
+  if (size > 1) {  // MPI all_gather of the rows (geneo.cpp:1151-1160) through one all-reduce
+    double* dc = (double*)bk::alloc(sizeof(double) * c.size());
+    bk::h2d(dc, c.data(), sizeof(double) * c.size());
+    allreduce(dc, (int)c.size());
+    bk::d2h(c.data(), dc, sizeof(double) * c.size());
+    bk::dfree(dc);
+  }
+  std::vector<double> f(Pn), mth((size_t)Pn * Pn);
+  for (int r = 0; r < Pn; ++r) {
+    double sum = 0.0;
+    for (int q = 0; q < Pn; ++q) sum += c[(size_t)r * Pn + q];
+    f[r] = 1.0 / sum;
+  }
+  for (int r = 0; r < Pn; ++r)
+    for (int q = 0; q < Pn; ++q)
+      mth[(size_t)r * Pn + q] = 0.5 * (c[(size_t)r * Pn + q] + c[(size_t)q * Pn + r]) * f[r] * f[q];
+  std::vector<double> w, V;
+  dense::sym_eig(mth, Pn, w, V);
+  double lmax = w[0];
+  for (double v : w)
+    if (std::fabs(v) > std::fabs(lmax)) lmax = v;
+  for (int s = 0; s < ns; ++s) {
+    double g = opt.gamma / lmax;
+    g = g * f[subs[s].gid] * f[subs[s].gid];
+    if (g <= 1.0) g = 1.1;
+    gammaLoc[s] = g;
+  }
+  return 0;
+}
+
+// GenEO-1: A_Neu v = lambda (D A_Dir D) v, lambda <= tau.   GenEO-2 (geneo.cpp:1274-1300): A_Neu v = lambda A_Rob v,
+// lambda <= tau_loc, then (D A_Dir D) v = lambda A_Rob v, lambda >= gamma_loc -- the LARGEST eigenvalues, computed
+// as the lowest mu = 1/lambda of A_Rob v = mu (D A_Dir D) v with the V-cycle of A_Rob as preconditioner.
+int PC::eigen_lobpcg() {
+  const int ns = (int)subs.size();
+  const bool g2 = (opt.lvl2 == 2);
+  int nev_try = 0;
+  const int m = eig_targets(&nev_try);
+  if (m != 16 && m != 32 && m != 64) return fail("GenEO: -els2_eps_block must be 16, 32 or 64");
+  if (nev_try > m) return fail("GenEO: -geneo_cut / -els2_eps_nev larger than the LOBPCG block (max 64)");
+  auto dv = [](size_t n) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, n)); };
+  // B = D A_Dir D always uses the true Dirichlet matrix: rebuild if level 1 holds the Robin one
+  bk::Csr dirB = dirL;
+  bool own_dirB = false;
+  if (opt.lvl1ORAS) {
+    std::vector<const HostCsr*> dm(ns);
+    for (int s = 0; s < ns; ++s) dm[s] = &subs[s].a_dir;
+    dirB = upload_blockdiag(dm, suboff, nullptr);
+    own_dirB = true;
+  }
+  double* Xt = dv((size_t)nL * m);
+  double* Xg = g2 ? dv((size_t)nL * m) : nullptr;
+  auto release = [&]() {
+    bk::dfree(Xt);
+    if (Xg) bk::dfree(Xg);
+    if (own_dirB) bk::csr_free(dirB);
+  };
+  info.eig_iterations = 0;
+  std::vector<double> lamT, muG;
+  {
+    EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirB, g2 ? nullptr : d_D, (opt.els2_pc == "amg") ? amgN : nullptr,
+                  d_dinvN, cheb_lmax, nev_try, "tau"};
+    if (int rc = lobpcg_solve(pt, m, lamT, Xt)) { release(); return rc; }
+  }
+  if (g2) {
+    if (int rc = local_gamma()) { release(); return rc; }
+    EigProblem pg{&dirL, nullptr, &dirB, d_D, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
+                  d_dinv1, cheb_lmax1, nev_try, "gamma"};
+    if (int rc = lobpcg_solve(pg, m, muG, Xg)) { release(); return rc; }
+  }
   // ---- selection (geneo.cpp:709-722), Nicolaides (:897-944), empty-Z rule (:1305-1314)
-  std::vector<int> sel((size_t)ns * m, 0);
+  std::vector<int> selT((size_t)ns * m, 0), selG((size_t)ns * m, 0), kT(ns, 0), kG(ns, 0);
+  std::vector<double> gscale((size_t)ns * m, 1.0);
   ksub.assign(ns, 0);
   double* ones = d_cg_p;
   double* tmp = d_cg_q;
   bk::set(ones, 1.0, nL);
   bk::spmv(neuL, ones, tmp);
-  std::vector<double> numv(ns), denv(ns);
   bk::seg_dot(ch, tmp, ones, d_cg_sc, 8, 0);
-  bk::xmy(d_cg_r, ones, d_D, nL);
-  bk::spmv(dirB, d_cg_r, tmp);
-  bk::xmy(tmp, tmp, d_D, nL);
+  if (g2) {
+    bk::spmv(dirL, ones, tmp);
+  } else {
+    bk::xmy(d_cg_r, ones, d_D, nL);
+    bk::spmv(dirB, d_cg_r, tmp);
+    bk::xmy(tmp, tmp, d_D, nL);
+  }
   bk::seg_dot(ch, tmp, ones, d_cg_sc, 8, 1);
   std::vector<double> sc((size_t)8 * ns);
   bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
   for (int s = 0; s < ns; ++s) {
+    const int nev = std::min(nev_try, (int)subs[s].l2g.size());
     int cnt = 0;
     double minval = 1e300;
-    for (int j = 0; j < nev_s[s]; ++j) {
-      const double l = lam[(size_t)s * m + j];
+    for (int j = 0; j < nev; ++j) {
+      const double l = lamT[(size_t)s * m + j];
       if (l >= 1e299) continue;
       candidates[s].push_back(l);
-      if (l > opt.tau) continue;
-      sel[(size_t)s * m + cnt++] = j;
+      if (l > tauLoc[s]) continue;
+      selT[(size_t)s * m + cnt++] = j;
       eigvals[s].push_back(l);
       minval = std::min(minval, l);
     }
-    info.estimDimELoc += cnt;
     if (cnt > 0 && minval >= DBL_EPSILON) {
       const double ratio = std::fabs(sc[(size_t)s * 8 + 0] / sc[(size_t)s * 8 + 1]);
       if (ratio <= FLT_EPSILON) {
-        sel[(size_t)s * m + cnt++] = -1;
+        selT[(size_t)s * m + cnt++] = -1;
         eigvals[s].push_back(0.0);
         info.nicolaidesLoc++;
       }
     }
-    if (cnt == 0) {
-      sel[(size_t)s * m + cnt++] = -1;
+    kT[s] = cnt;
+    int cg = 0;
+    if (g2) {
+      for (int j = 0; j < nev; ++j) {
+        const double mu = muG[(size_t)s * m + j];
+        if (mu >= 1e299 || !(mu > 0.0)) continue;
+        const double l = 1.0 / mu;
+        candidates[s].push_back(l);
+        if (l < gammaLoc[s]) continue;
+        gscale[(size_t)s * m + j] = std::sqrt(l);  // SLEPc normalisation v^T A_Rob v = 1 (ours: v^T B_w v = 1)
+        selG[(size_t)s * m + cg++] = j;
+        eigvals[s].push_back(l);
+      }
+    }
+    if (cnt + cg == 0) {
+      selT[(size_t)s * m + cnt++] = -1;
       eigvals[s].push_back(0.0);
       info.nicolaidesLoc++;
+      kT[s] = cnt;
     }
-    ksub[s] = cnt;
+    kG[s] = cg;
+    info.estimDimELoc += cnt + cg;
+    ksub[s] = cnt + cg;
   }
-  std::vector<int64_t> zbase(ns + 1, 0);
-  for (int s = 0; s < ns; ++s) zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
+  std::vector<int64_t> zbase(ns + 1, 0), zbaseG(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) {
+    zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
+    zbaseG[s] = zbase[s] + (int64_t)kT[s] * (int64_t)subs[s].l2g.size();
+  }
   d_Z = (double*)bk::alloc(sizeof(double) * (size_t)std::max<int64_t>(1, zbase[ns]));
   d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
-  bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
-  int* dsel = (int*)bk::alloc(sizeof(int) * sel.size());
+  int64_t* dzb = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
+  int* dsel = (int*)bk::alloc(sizeof(int) * selT.size());
   int* dks = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
-  bk::h2d(dsel, sel.data(), sizeof(int) * sel.size());
-  bk::h2d(dks, ksub.data(), sizeof(int) * ns);
-  bk::block_extract(ch, S, p3, m, d_D, dsel, dks, d_zbase, d_Z);
+  bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
+  bk::h2d(dsel, selT.data(), sizeof(int) * selT.size());
+  bk::h2d(dks, kT.data(), sizeof(int) * ns);
+  bk::block_extract(ch, Xt, m, m, d_D, dsel, dks, d_zbase, d_Z);
   bk::sync();
+  if (g2) {
+    double* dgs = dv(gscale.size());
+    bk::h2d(dgs, gscale.data(), sizeof(double) * gscale.size());
+    bk::block_colscale(ch, Xg, m, m, dgs);
+    bk::h2d(dzb, zbaseG.data(), sizeof(int64_t) * (ns + 1));
+    bk::h2d(dsel, selG.data(), sizeof(int) * selG.size());
+    bk::h2d(dks, kG.data(), sizeof(int) * ns);
+    bk::block_extract(ch, Xg, m, m, d_D, dsel, dks, dzb, d_Z);
+    bk::sync();
+    bk::dfree(dgs);
+  }
+  bk::dfree(dzb);
   bk::dfree(dsel);
   bk::dfree(dks);
-  cleanup();
-  if (own_dirB) bk::csr_free(dirB);
+  release();
   return 0;
 }
 

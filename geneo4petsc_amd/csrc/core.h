@@ -93,6 +93,7 @@ class PC {
     std::vector<int> l2g;    // dofIdxDomLoc (ascending global ids)
     std::vector<int> mult;   // dofIdxMultLoc
     HostCsr a_neu, a_dir;    // MATIS local matrix / optional pcADirLoc
+    std::vector<char> intersect;  // intersectLoc emptiness per global subdomain (GenEO-2 gamma_loc only)
   };
   std::vector<Sub> subs;
   // halo plan (size > 1)
@@ -106,6 +107,7 @@ class PC {
   ~PC();
   int add_subdomain(int gid, int n, const int* l2g, const int* mult, const int* neu_rowptr, const int* neu_col,
                     const double* neu_val, const int* dir_rowptr, const int* dir_col, const double* dir_val);
+  int set_intersect(int gid, int nb, const int* nonempty);   // intersectLoc of initGenEOPC (hdr/geneo.hpp:34)
   int setup(const double* b_dev);                       // setUpGenEOPC, geneo.cpp:1672
   int apply(const double* x_dev, double* y_dev);        // applyGenEOPC, geneo.cpp:2051
   int apply_q(const double* x_dev, double* y_dev);      // applyQ, geneo.cpp:1435
@@ -119,6 +121,7 @@ class PC {
   std::vector<double> E;                         // dimE x dimE (row-major)
   std::vector<int> ksub_global;                  // realDimE per global subdomain
   std::vector<double> residual_history;
+  std::vector<double> tauLoc, gammaLoc;          // per local subdomain (GenEO-2, geneo.cpp:1097-1232)
 
  private:
   bool is_setup = false;
@@ -145,7 +148,7 @@ class PC {
   std::vector<int> Epiv;
   bool E_chol = true;
   std::vector<double> h_yE;
-  double cheb_lmax = 2.0;
+  double cheb_lmax = 2.0, cheb_lmax1 = 2.0;
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 
@@ -154,6 +157,18 @@ class PC {
   int ensure_dirichlet();
   void make_robin(Sub& s, HostCsr& out) const;
   int setup_level2(const double* b_dev);
+  struct EigProblem {
+    const bk::Csr* A; const double* As;   // Y = As .* A (As .* X); As may be null
+    const bk::Csr* B; const double* Bs;
+    AmgDevice* amg;                       // V-cycle of A as preconditioner (null: Chebyshev-Jacobi)
+    const double* dinv; double lmax;      // Jacobi scaling and Gershgorin bound for the Chebyshev fallback
+    int nev_try;
+    const char* label;
+  };
+  int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
+  int eig_targets(int* nev_try) const;
+  void local_tau();
+  int local_gamma();
   int eigen_dense_host();
   int eigen_lobpcg();
   int build_E();

@@ -143,7 +143,7 @@ class GenEOPC:
     def init(self, nbDOF, nbDOFLoc, pcMap, pcA, pcADirLoc, pcB, pcX0, dofIdxDomLoc, dofIdxMultLoc,
              intersectLoc=None):
         """initGenEOPC (hdr/geneo.hpp:30-35): one subdomain for this rank.  pcB: DeviceVector or None."""
-        del pcX0, dofIdxDomLoc, intersectLoc   # x0 is produced by setup; the map carries the DOF ids
+        del pcX0, dofIdxDomLoc   # x0 is produced by setup; the map carries the DOF ids
         l2g = np.ascontiguousarray(pcMap, dtype=np.int32)
         mult = np.ascontiguousarray(dofIdxMultLoc, dtype=np.uint32)
         an = _csr_arrays(pcA)
@@ -159,6 +159,8 @@ class GenEOPC:
                                          C.byref(sn), C.byref(sd) if sd is not None else None,
                                          pcB.ptr if pcB is not None else None, None,
                                          mult.ctypes.data_as(C.POINTER(C.c_uint))))
+        if intersectLoc is not None:
+            self.set_intersect(getattr(self, "rank", 0), [len(x) > 0 for x in intersectLoc])
 
     def set_comm(self, rank, size, owned_gid, halo_gid, recv_counts, send_counts, send_idx, exchange, allreduce,
                  send_ptr, recv_ptr, red_ptr, red_capacity):
@@ -172,6 +174,7 @@ class GenEOPC:
                                           p(halo_gid), p(recv_counts), p(send_counts), p(send_idx), self._cb[0],
                                           self._cb[1], None, send_ptr, recv_ptr, red_ptr, int(red_capacity)))
         self.n_owned = len(owned_gid)
+        self.rank = int(rank)
 
     # -- PC ops ------------------------------------------------------------------------------
     def setup(self, b=None):
@@ -241,6 +244,18 @@ class GenEOPC:
         out = np.zeros(max(1, d * d))
         self.lib.PCGenEOGetE(self.h, out.ctypes.data_as(L.c_dbl_p), d * d)
         return out[:d * d].reshape(d, d)
+
+    def set_intersect(self, gid, nonempty):
+        """intersectLoc emptiness flags of subdomain gid (initGenEOPC, hdr/geneo.hpp:34); GenEO-2 only."""
+        f = np.ascontiguousarray(nonempty, dtype=np.int32)
+        self._chk(self.lib.PCGenEOSetIntersect(self.h, int(gid), len(f), f.ctypes.data_as(L.c_int_p)))
+
+    def local_params(self):
+        """(tau_loc, gamma_loc) per local subdomain (getLocalGenEOTau / Gamma, geneo.cpp:1097-1232)."""
+        n = self.lib.PCGenEOGetLocalParams(self.h, None, None, 0)
+        t, g = np.zeros(max(1, n)), np.zeros(max(1, n))
+        self.lib.PCGenEOGetLocalParams(self.h, t.ctypes.data_as(L.c_dbl_p), g.ctypes.data_as(L.c_dbl_p), n)
+        return t[:n], g[:n]
 
     def local_dims(self):
         n = self.lib.PCGenEOGetLocalDims(self.h, None, 0)

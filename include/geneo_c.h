@@ -99,6 +99,11 @@ PetscErrorCode PCGenEOSetSizes(PC pc, int nbDOF, int nbSubdomainsGlobal);
 PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int nbDOFLoc, const int* map, const int* multiplicity,
                                    const GeneoCsr* A_local, const GeneoCsr* ADirLoc);
 
+/* intersectLoc of initGenEOPC (hdr/geneo.hpp:34): nonempty[q] != 0 iff subdomain gid shares DOFs with
+ * subdomain q.  Only GenEO-2's gamma_loc reads it (src/geneo.cpp:1139-1148); on one rank it is derived
+ * from the maps when absent. */
+PetscErrorCode PCGenEOSetIntersect(PC pc, int gid, int nbSubdomainsGlobal, const int* nonempty);
+
 /* ---- multi-rank plumbing (one process per GPU; the transport is supplied by the host) ----- */
 typedef int (*GeneoExchangeFn)(void* user, int reverse);  /* 0 = forward (owner -> halo), 1 = reverse */
 typedef int (*GeneoAllreduceFn)(void* user, int n);       /* in-place sum of red_dev[0..n) over ranks */
@@ -145,6 +150,8 @@ int PCGenEOGetCandidates(PC pc, int local_sub, double* vals, int cap);
 /* coarse operator E (dimE x dimE row-major); returns dimE */
 int PCGenEOGetE(PC pc, double* e, int cap);
 int PCGenEOGetLocalDims(PC pc, int* ksub_global, int cap);
+/* tau_loc / gamma_loc per local subdomain (getLocalGenEOTau / Gamma, src/geneo.cpp:1097-1232); returns the count */
+int PCGenEOGetLocalParams(PC pc, double* tau_loc, double* gamma_loc, int cap);
 
 /* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
 const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */

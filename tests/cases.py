@@ -38,13 +38,15 @@ def ksp_args(argv):
     return ksp, out
 
 
-def run_pc(lib, mesh, dec, argv, b, with_dir=True):
+def run_pc(lib, mesh, dec, argv, b, with_dir=True, with_intersect=False):
     from geneo4petsc_amd.pc import GenEOPC
     pc = GenEOPC(lib)
     pc.set_from_options(argv)
     pc.set_sizes(mesh.nbNode, len(dec.domains))
     for d in dec.domains:
         pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir if with_dir else None)
+        if with_intersect:
+            pc.set_intersect(d.gid, [len(x) > 0 for x in d.intersect])
     pc.setup(b)
     return pc
 
@@ -58,13 +60,13 @@ def graph_case(size=400, level=2, nb=4, overlap=1, no_ground=True):
 
 
 def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, xtol=1e-8, aptol=1e-9, case=None,
-                        dim=3):
+                        dim=3, with_intersect=False):
     """Full parity check of one configuration: integer outputs exact, floats within tolerance."""
     if case is not None:
         mesh, dec, a, b = case
     else:
         mesh, dec, a, b = grid_case(n=n, dim=dim, parts=parts, overlap=overlap, **(gen or {}))
-    pc = run_pc(lib, mesh, dec, argv, b, with_dir)
+    pc = run_pc(lib, mesh, dec, argv, b, with_dir, with_intersect)
     orc = oracle_for(mesh, dec, argv, b)
     ksp, kw = ksp_args(argv)
     res = go.solve(orc, b, ksp, **kw)
@@ -87,6 +89,10 @@ def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, x
         assert list(pc.local_dims()) == orc.realDimELoc                                  # integer selection
         assert info["nicolaidesLoc"] == sum(orc.nicolaidesLoc)
         assert info["dimE"] == orc.dimE
+        if orc.o.lvl2 == 2 and not orc.o.cst:                                            # geneo.cpp:1097-1232
+            t, g = pc.local_params()
+            np.testing.assert_allclose(t, orc.tauLoc, rtol=1e-14)
+            np.testing.assert_allclose(g, orc.gammaLoc, rtol=1e-12)
         for s in range(len(dec.domains)):
             ev = np.sort(pc.eigenvalues(s))
             np.testing.assert_allclose(ev, np.sort(orc.eigvals[s]), rtol=1e-10, atol=1e-13)  # 1e-10 relative

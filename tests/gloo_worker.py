@@ -16,13 +16,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     out_path, lvl, ksp = sys.argv[1], sys.argv[2], sys.argv[3]
+    parts = tuple(int(t) for t in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 2, 2)
+    extra = sys.argv[5:]
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     import hostsim_util as hu
     from geneo4petsc_amd import decomp
     from geneo4petsc_amd.comm import TorchComm, gather_owned
     from geneo4petsc_amd.pc import GenEOPC
-    n, parts, ov = 12, (2, 2, 2), 1
+    n, ov = 12, 1
     nb = 8
     sub_rank = np.arange(nb) * size // nb
     doms = [decomp.decompose_grid_domain(n, 3, parts, ov, s) for s in range(nb) if sub_rank[s] == rank]
@@ -31,11 +33,13 @@ def main():
     comm = TorchComm(plan, "cpu")
     pc = GenEOPC(lib)
     pc.set_from_options(["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp,
-                         "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"])
+                         "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"] + extra)
     pc.set_sizes(n ** 3, nb)
     comm.attach(pc)
     for d in doms:
         pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+        if lvl.endswith("2"):      # intersectLoc emptiness (GenEO-2 gamma_loc): required on several ranks
+            pc.set_intersect(d.gid, [len(x) > 0 for x in d.intersect])
     # b = A (1..N) on the owned rows, from the Dirichlet rows of the domain that owns each node
     xstar = np.arange(1.0, n ** 3 + 1.0)
     b = np.zeros(len(plan.owned))
@@ -48,7 +52,8 @@ def main():
     x, its, rnorm, reason = pc.solve(b)
     y = pc.apply(b)
     m = pc.matmult(b)
-    res = dict(its=its, reason=reason, dims=[int(v) for v in pc.local_dims()], dimE=pc.info()["dimE"])
+    res = dict(its=its, reason=reason, dims=[int(v) for v in pc.local_dims()], dimE=pc.info()["dimE"],
+               gamma=[float(v) for v in pc.local_params()[1]])
     xf = gather_owned(x, plan, n ** 3)
     yf = gather_owned(y, plan, n ** 3)
     mf = gather_owned(m, plan, n ** 3)

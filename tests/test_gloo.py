@@ -14,25 +14,29 @@ from oracle import geneo_oracle as go
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("lvl,ksp", [("ASM,1", "cg"), ("RAS,H1", "gmres")])
-def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp):
+@pytest.mark.parametrize("lvl,ksp,parts,extra", [
+    ("ASM,1", "cg", (2, 2, 2), []), ("RAS,H1", "gmres", (2, 2, 2), []),
+    ("SORAS,2", "cg", (4, 2, 1), ["-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", "12", "-geneo_optim", "0.5"])])
+def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "gloo_worker.py"),
-           out, lvl, ksp]
+           out, lvl, ksp, ",".join(str(p) for p in parts)] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = np.load(out)
     meta = json.loads(str(got["meta"]))
-    mesh, dec, a, b = cases.grid_case(12, 3, (2, 2, 2), 1)
+    mesh, dec, a, b = cases.grid_case(12, 3, parts, 1)
     np.testing.assert_allclose(got["b"], b, rtol=1e-13)
     argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp, "-els2_eps_tol", "1e-10",
-            "-ksp_rtol", "1e-8"]
+            "-ksp_rtol", "1e-8"] + extra
     orc = cases.oracle_for(mesh, dec, argv, b)
     kspname, kw = cases.ksp_args(argv)
     res = go.solve(orc, b, kspname, **kw)
     assert meta["dims"] == orc.realDimELoc and meta["dimE"] == orc.dimE
+    if lvl.endswith("2"):      # rank 0 holds subdomains 0..3: gamma_loc from the all-reduced connectivity matrix
+        np.testing.assert_allclose(meta["gamma"], orc.gammaLoc[:len(meta["gamma"])], rtol=1e-12)
     assert meta["reason"] == res.reason
     assert abs(meta["its"] - res.its) <= (2 if ksp == "cg" else 0)
     np.testing.assert_allclose(got["m"], orc.matmult(b), rtol=1e-12, atol=1e-9)

@@ -30,6 +30,19 @@ def test_modes_match_oracle(lib, lvl, ksp, overlap):
     cases.compare_with_oracle(lib, 12, (2, 2, 2), overlap, argv)
 
 
+@pytest.mark.parametrize("lvl,ksp,n,parts,cut,inter", [("SORAS,2", "cg", 12, (3, 2, 1), 12, True),
+                                                       ("ORAS,H2", "gmres", 10, (2, 2, 2), 10, False),
+                                                       ("SORAS,E2", "cg", 6, (2, 2, 1), 12, False),
+                                                       ("SORAS,2", "cg", 16, (2, 2, 2), 10, False)])
+def test_geneo2_matches_oracle(lib, lvl, ksp, n, parts, cut, inter):
+    """GenEO-2 (geneo.cpp:1274-1300): tau problem on (A_Neu, A_Rob) with tau_loc and gamma problem on
+    (D A_Dir D, A_Rob) with gamma_loc -- the largest eigenvalues, computed by LOBPCG on the inverted pencil."""
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", str(cut), "-geneo_optim", "0.5",
+            "-ksp_type", ksp] + TIGHT
+    _, info = cases.compare_with_oracle(lib, n, parts, 1, argv, with_intersect=inter)
+    assert info["dimE"] > len(parts)
+
+
 def test_config0_laplacian_2d_two_subdomains_five_vectors(lib):
     """BASELINE configs[0]: tst/laplacian 2-D stencil, 2 subdomains, 5 eigenvectors per subdomain."""
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "5", "-ksp_type", "gmres"] + TIGHT

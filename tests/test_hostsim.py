@@ -23,6 +23,25 @@ def test_modes(lib, lvl, ksp, overlap):
     cases.compare_with_oracle(lib, 12, (2, 2, 2), overlap, argv)
 
 
+@pytest.mark.parametrize("lvl,ksp,n,parts,cut,inter", [("SORAS,2", "cg", 12, (3, 2, 1), 12, True),
+                                                       ("ORAS,H2", "gmres", 10, (2, 2, 2), 10, False),
+                                                       ("SORAS,E2", "cg", 6, (2, 2, 1), 12, False)])
+def test_geneo2(lib, lvl, ksp, n, parts, cut, inter):
+    """GenEO-2 (geneo.cpp:1274-1300): tau problem on (A_Neu, A_Rob) with tau_loc, gamma problem on (D A_Dir D, A_Rob)
+    with gamma_loc from the connectivity matrix, -geneo_cut halved.  gamma 1.05 makes the gamma problem contribute
+    vectors; n = 6 runs the dense small-subdomain path, the others LOBPCG (inverted pencil for the largest ones)."""
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", str(cut), "-geneo_optim", "0.5",
+            "-ksp_type", ksp] + TIGHT          # cut chosen so that cut/2 does not fall inside a multiplet
+    _, info = cases.compare_with_oracle(lib, n, parts, 1, argv, with_intersect=inter)
+    assert info["dimE"] > len(parts)
+
+
+def test_geneo2_cst_and_chebyshev_fallback(lib):
+    argv = ["-geneo_lvl", "SORAS,2", "-geneo_tau", "0.05", "-geneo_gamma", "1.2", "-geneo_cst", "-geneo_cut", "8",
+            "-geneo_optim", "0.1", "-ksp_type", "cg", "-els2_pc_type", "cheb", "-dls1_pc_type", "jacobi"] + TIGHT
+    cases.compare_with_oracle(lib, 10, (2, 2, 1), 1, argv)
+
+
 def test_multilevel_amg_inner_preconditioner(lib):
     """Two-level smoothed-aggregation hierarchy inside the local PCG and inside LOBPCG: same outer
     operator as the oracle's exact LU (parity unchanged), far fewer inner iterations than Jacobi."""
@@ -69,7 +88,10 @@ def test_option_errors(lib):
     pc3.set_from_options(["-geneo_lvl", "ASM,2"])
     with pytest.raises(GenEOError):
         pc3.set_sizes(4, 1)
-        pc3.setup()                                       # no subdomain / GenEO-2 not built: loud error
+        pc3.setup()                                       # no subdomain: loud error
+    mesh, dec, a, b = cases.grid_case(6, 3, (2, 1, 1), 1)
+    with pytest.raises(GenEOError, match="GenEO-2 needs the Robin matrix"):
+        cases.run_pc(lib, mesh, dec, ["-geneo_lvl", "ASM,2"], b)
 
 
 @pytest.mark.parametrize("rec", [r for r in dc.geneo_refs() if r["geneo_lvl"].startswith("ASM")][::3],
