@@ -142,10 +142,17 @@ const char* usageGenEO_c(void) {
          "  -geneo_gamma G   gamma threshold (defaults to 10.)\n"
          "  -geneo_cst       do not allow local variations of tau and gamma (GenEO-2)\n"
          "  -geneo_cut C     maximum number of local eigen vectors used to build Z\n"
-         "  -geneo_no_syl    accepted for compatibility (no inertia estimate on the GPU path)\n"
+         "                   (without it every eigenvalue below tau is kept: the LOBPCG block grows up to 64 columns)\n"
+         "  -geneo_no_syl    ask for -els2_eps_nev eigenvalues instead (no inertia estimate exists on the GPU path)\n"
          "  -geneo_offload   accepted for compatibility (E is replicated on every GPU)\n"
-         "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_cheb_degree / -els2_cheb_ratio\n"
-         "  -dls1_ksp_rtol / -dls1_ksp_max_it   local solves (batched Jacobi-PCG)\n"
+         "  -geneo_chk F     perform additional checks (F = log | bin | mat; files are text)\n"
+         "                     - check partition of unity\n"
+         "                     - check matrices are SPD (check.SPD.A.log, check<id>.SPD.<pb>.B.log)\n"
+         "                     - check R from Z=QR (check<id>.setup.Z.R, check.setup.ZE2G.R)\n"
+         "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_pc_type amg|cheb\n"
+         "  -els2_cheb_degree / -els2_cheb_ratio\n"
+         "  -dls1_ksp_rtol / -dls1_ksp_max_it / -dls1_pc_type amg|jacobi   local solves (batched PCG)\n"
+         "  -amg_coarse_size / -amg_smooth_degree / -amg_smooth_ratio / -amg_max_levels\n"
          "  -ksp_type cg|gmres -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart\n\n";
 }
 

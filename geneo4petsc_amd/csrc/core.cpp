@@ -22,6 +22,8 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <fstream>
+#include <iomanip>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -108,6 +110,11 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   if (key == "-geneo_cst") { o.cst = true; return ""; }
   if (key == "-geneo_no_syl") { o.noSyl = true; return ""; }
   if (key == "-geneo_offload") { o.offload = true; return ""; }
+  if (key == "-geneo_chk") {  // geneo.cpp:2466-2479 (bin / mat select PETSc viewers there; files are text here)
+    if (value != "log" && value != "bin" && value != "mat") return "invalid option -geneo_chk, unknown " + value;
+    o.check = true;
+    return "";
+  }
   if (key == "-els2_eps_tol") return dbl(o.eps_tol);
   if (key == "-els2_eps_nev") return integer(o.eps_nev);
   if (key == "-els2_eps_max_it") return integer(o.eps_max_it);
@@ -155,6 +162,7 @@ std::string validate_options(const Options& o) {  // geneo.cpp:2486-2488
 }
 
 // ------------------------------------------------------------------------------------ helpers
+static std::string check_id(int gid, int nsub);
 int PC::fail(const std::string& msg) {
   last_error = msg;
   return 1;
@@ -556,12 +564,12 @@ int PC::setup(const double* b_dev) {
       if (want1) {
         amg1 = new AmgDevice();
         // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
-        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_targets(nullptr) : 1, &dirL);
+        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
         info.amg_levels = amg1->nlevels();
         info.amg_operator_complexity = amg1->operator_complexity();
       }
       if (wantN) {
-        const int max_m = eig_targets(nullptr);
+        const int max_m = eig_block_max();
         amgN = new AmgDevice();
         amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, max_m, &neuL);
         if (!want1) {
@@ -582,6 +590,17 @@ int PC::setup(const double* b_dev) {
   info.lvl1SetupMinvTimeLoc = secs(t1, clk::now());
   is_setup = true;
   bk::set(d_x0, 0.0, n_owned());
+  if (opt.check) {
+    for (auto& s : subs)                      // geneo.cpp:988-997 (D = 1/mult, mult >= 1 validated on input)
+      for (int v : s.mult)
+        if (1.0 / (double)v <= DBL_EPSILON) return fail("GenEO - check D: bad partition of unity, min 0");
+    try {
+      if (int rc = check_global_spd()) { is_setup = false; return rc; }
+    } catch (std::exception& e) {
+      is_setup = false;
+      return fail(e.what());
+    }
+  }
   if (opt.lvl2) {
     if (int rc = setup_level2(b_dev)) {
       is_setup = false;
@@ -794,7 +813,11 @@ int PC::setup_level2(const double* b_dev) {
   auto t1 = clk::now();
   info.lvl2SetupEigTimeLoc = secs(t0, t1);
   try {
+    if (opt.check)
+      if (int rc = check_local_rank()) return rc;
     if (int r2 = build_E()) return r2;
+    if (opt.check)
+      if (int rc = check_global_rank()) return rc;
   } catch (std::exception& e) {
     return fail(e.what());
   }
@@ -838,9 +861,45 @@ int PC::eigen_dense_host() {
       densify(rob, nullptr, GR);
     }
     const std::vector<double>& GB = g2 ? GR : GW;
+    if (opt.check) {  // checkSPD of the pencil's right-hand matrix (geneo.cpp:883-886), dense here
+      for (const char* pb : {"tau", "gamma"}) {
+        if (!g2 && pb[0] == 'g') break;
+        std::vector<double> G = GB, w, V;
+        dense::sym_eig(G, n, w, V);
+        int neg = 0, nul = 0, pos = 0;
+        double wmax = 0.0, wmin = 1e300;
+        for (double v : w) { wmax = std::max(wmax, std::fabs(v)); wmin = std::min(wmin, v); }
+        for (double v : w) {
+          if (std::fabs(v) <= 1e-14 * wmax) nul++;
+          else if (v < 0) neg++;
+          else pos++;
+        }
+        std::ofstream f((check_id(sd.gid, nsub_global) + ".SPD." + pb + ".B.log").c_str());
+        f << pb << ".B - eigen value 0: " << wmin << std::endl;
+        f << std::endl << pb << ".B - inertia: nbNegEV " << neg << ", nbNullEV " << nul << ", nbPosEV " << pos << std::endl;
+        if (std::fabs(wmin) <= DBL_EPSILON) {
+          std::ostringstream msg;
+          msg << "GenEO - check SPD: " << pb << ".B not SPD, bad eigen value " << wmin;
+          return fail(msg.str());
+        }
+        if (neg > 0 || nul > 0) return fail("GenEO - check SPD: not SPD (inertia - negative or null eigen value found)");
+      }
+    }
     std::vector<double> th, C;
     int r = dense::gen_eig_rr(GA, GB, n, 0, 1e-13, th, C);
-    int nev = std::min(std::min(nev_try, n), r);
+    // eigenLocalProblem :855-879 with the inertia count read off the full spectrum
+    auto nev_for = [&](int est) {
+      int nev = nev_try;
+      if (!opt.noSyl && est > 0) {
+        nev = est;
+        const int cut = (g2 && opt.cut >= 2) ? opt.cut / 2 : opt.cut;
+        if (cut > 0) nev = std::min(nev, cut);
+      }
+      return nev;
+    };
+    int est = 0;
+    for (int j = 0; j < r; ++j) est += (th[j] < tauLoc[s]);
+    int nev = std::min(std::min(nev_for(est), n), r);
     // TARGET_MAGNITUDE around 0 (geneo.cpp:638-640): smallest |theta| first
     std::vector<int> ord(r);
     std::iota(ord.begin(), ord.end(), 0);
@@ -866,7 +925,9 @@ int PC::eigen_dense_host() {
     }
     if (g2) {  // gamma problem (geneo.cpp:1299): largest eigenvalues of B_w v = lambda A_Rob v, kept when >= gamma_loc
       r = dense::gen_eig_rr(GW, GR, n, 0, 1e-13, th, C);
-      nev = std::min(std::min(nev_try, n), r);
+      est = 0;
+      for (int j = 0; j < r; ++j) est += (th[j] > gammaLoc[s]);
+      nev = std::min(std::min(nev_for(est), n), r);
       ord.resize(r);
       std::iota(ord.begin(), ord.end(), 0);
       std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(th[a]) > std::fabs(th[b]); });
@@ -1116,6 +1177,12 @@ int PC::eig_targets(int* nev_try) const {
   return want <= 16 ? 16 : (want <= 32 ? 32 : 64);
 }
 
+// widest block the eigensolver may use (sizes the V-cycle work space): without -geneo_cut the block can grow to 64
+int PC::eig_block_max() const {
+  if (opt.cut <= 0 && !opt.noSyl && opt.eps_block <= 0) return 64;
+  return eig_targets(nullptr);
+}
+
 // getLocalGenEOTau, geneo.cpp:1097-1118
 void PC::local_tau() {
   const int ns = (int)subs.size();
@@ -1203,29 +1270,80 @@ int PC::eigen_lobpcg() {
     dirB = upload_blockdiag(dm, suboff, nullptr);
     own_dirB = true;
   }
-  double* Xt = dv((size_t)nL * m);
-  double* Xg = g2 ? dv((size_t)nL * m) : nullptr;
+  double *Xt = nullptr, *Xg = nullptr;
   auto release = [&]() {
-    bk::dfree(Xt);
+    if (Xt) bk::dfree(Xt);
     if (Xg) bk::dfree(Xg);
     if (own_dirB) bk::csr_free(dirB);
   };
   info.eig_iterations = 0;
   std::vector<double> lamT, muG;
+  std::vector<HostCsr> robh;
+  std::vector<const HostCsr*> hostB(ns);
+  if (opt.check) {   // host copies of the pencils' right-hand matrices for checkSPD
+    if (g2) robh.resize(ns);
+    for (int s = 0; s < ns; ++s) {
+      if (g2) {
+        make_robin(subs[s], robh[s]);
+        hostB[s] = &robh[s];
+      } else {
+        hostB[s] = &subs[s].a_dir;
+      }
+    }
+  }
+  // Without -geneo_cut the reference keeps EVERY eigenvalue on the wanted side of the threshold (its nev is
+  // the LDLt inertia count, geneo.cpp:502-560).  There is no inertia count here: when the whole block lands
+  // on the wanted side, the block is doubled and the problem solved again (loud error beyond 64 columns).
+  auto solve_grow = [&](EigProblem P, bool gamma, int& mm, int& nev, std::vector<double>& lam, double*& X) -> int {
+    mm = m;
+    nev = nev_try;
+    for (;;) {
+      P.nev_try = nev;
+      X = dv((size_t)nL * mm);
+      if (int rc = lobpcg_solve(P, mm, lam, X)) return rc;
+      if (opt.cut > 0 || opt.noSyl || opt.eps_block > 0) return 0;
+      bool full = false;
+      for (int s = 0; s < ns; ++s) {
+        const int n_s = (int)subs[s].l2g.size(), nv = std::min(nev, n_s);
+        if (nv >= n_s) continue;
+        const double last = lam[(size_t)s * mm + nv - 1];
+        if (last >= 1e299) continue;
+        if (gamma ? (last > 0.0 && 1.0 / last >= gammaLoc[s]) : (last <= tauLoc[s])) full = true;
+      }
+      if (!full) return 0;
+      if (nev >= 51)
+        return fail("GenEO: more than 51 eigenvalues pass the threshold in one subdomain and the LOBPCG block holds 64 "
+                    "columns: set -geneo_cut (or lower -geneo_tau)");
+      bk::dfree(X);
+      X = nullptr;
+      nev = std::min(51, 2 * nev);
+      const int want = nev + std::max(4, nev / 4);
+      mm = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
+    }
+  };
+  int m_t = m, m_g = m, nev_t = nev_try, nev_g = nev_try;
   {
     EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirB, g2 ? nullptr : d_D, (opt.els2_pc == "amg") ? amgN : nullptr,
                   d_dinvN, cheb_lmax, nev_try, "tau"};
-    if (int rc = lobpcg_solve(pt, m, lamT, Xt)) { release(); return rc; }
+    if (opt.check)
+      if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release(); return rc; }
+    if (int rc = solve_grow(pt, false, m_t, nev_t, lamT, Xt)) { release(); return rc; }
   }
   if (g2) {
     if (int rc = local_gamma()) { release(); return rc; }
     EigProblem pg{&dirL, nullptr, &dirB, d_D, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
                   d_dinv1, cheb_lmax1, nev_try, "gamma"};
-    if (int rc = lobpcg_solve(pg, m, muG, Xg)) { release(); return rc; }
+    if (opt.check) {  // the reference checks the B of the gamma pencil as given to SLEPc: A_Rob (geneo.cpp:1299,:884)
+      EigProblem pchk = pg;
+      pchk.B = &dirL;
+      pchk.Bs = nullptr;
+      if (int rc = check_local_spd(pchk, hostB.data(), false)) { release(); return rc; }
+    }
+    if (int rc = solve_grow(pg, true, m_g, nev_g, muG, Xg)) { release(); return rc; }
   }
   // ---- selection (geneo.cpp:709-722), Nicolaides (:897-944), empty-Z rule (:1305-1314)
-  std::vector<int> selT((size_t)ns * m, 0), selG((size_t)ns * m, 0), kT(ns, 0), kG(ns, 0);
-  std::vector<double> gscale((size_t)ns * m, 1.0);
+  std::vector<int> selT((size_t)ns * m_t, 0), selG((size_t)ns * m_g, 0), kT(ns, 0), kG(ns, 0);
+  std::vector<double> gscale((size_t)ns * m_g, 1.0);
   ksub.assign(ns, 0);
   double* ones = d_cg_p;
   double* tmp = d_cg_q;
@@ -1243,22 +1361,22 @@ int PC::eigen_lobpcg() {
   std::vector<double> sc((size_t)8 * ns);
   bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
   for (int s = 0; s < ns; ++s) {
-    const int nev = std::min(nev_try, (int)subs[s].l2g.size());
+    const int nevT = std::min(nev_t, (int)subs[s].l2g.size()), nevG = std::min(nev_g, (int)subs[s].l2g.size());
     int cnt = 0;
     double minval = 1e300;
-    for (int j = 0; j < nev; ++j) {
-      const double l = lamT[(size_t)s * m + j];
+    for (int j = 0; j < nevT; ++j) {
+      const double l = lamT[(size_t)s * m_t + j];
       if (l >= 1e299) continue;
       candidates[s].push_back(l);
       if (l > tauLoc[s]) continue;
-      selT[(size_t)s * m + cnt++] = j;
+      selT[(size_t)s * m_t + cnt++] = j;
       eigvals[s].push_back(l);
       minval = std::min(minval, l);
     }
     if (cnt > 0 && minval >= DBL_EPSILON) {
       const double ratio = std::fabs(sc[(size_t)s * 8 + 0] / sc[(size_t)s * 8 + 1]);
       if (ratio <= FLT_EPSILON) {
-        selT[(size_t)s * m + cnt++] = -1;
+        selT[(size_t)s * m_t + cnt++] = -1;
         eigvals[s].push_back(0.0);
         info.nicolaidesLoc++;
       }
@@ -1266,19 +1384,19 @@ int PC::eigen_lobpcg() {
     kT[s] = cnt;
     int cg = 0;
     if (g2) {
-      for (int j = 0; j < nev; ++j) {
-        const double mu = muG[(size_t)s * m + j];
+      for (int j = 0; j < nevG; ++j) {
+        const double mu = muG[(size_t)s * m_g + j];
         if (mu >= 1e299 || !(mu > 0.0)) continue;
         const double l = 1.0 / mu;
         candidates[s].push_back(l);
         if (l < gammaLoc[s]) continue;
-        gscale[(size_t)s * m + j] = std::sqrt(l);  // SLEPc normalisation v^T A_Rob v = 1 (ours: v^T B_w v = 1)
-        selG[(size_t)s * m + cg++] = j;
+        gscale[(size_t)s * m_g + j] = std::sqrt(l);  // SLEPc normalisation v^T A_Rob v = 1 (ours: v^T B_w v = 1)
+        selG[(size_t)s * m_g + cg++] = j;
         eigvals[s].push_back(l);
       }
     }
     if (cnt + cg == 0) {
-      selT[(size_t)s * m + cnt++] = -1;
+      selT[(size_t)s * m_t + cnt++] = -1;
       eigvals[s].push_back(0.0);
       info.nicolaidesLoc++;
       kT[s] = cnt;
@@ -1295,21 +1413,21 @@ int PC::eigen_lobpcg() {
   d_Z = (double*)bk::alloc(sizeof(double) * (size_t)std::max<int64_t>(1, zbase[ns]));
   d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
   int64_t* dzb = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
-  int* dsel = (int*)bk::alloc(sizeof(int) * selT.size());
+  int* dsel = (int*)bk::alloc(sizeof(int) * std::max(selT.size(), selG.size()));
   int* dks = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
   bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
   bk::h2d(dsel, selT.data(), sizeof(int) * selT.size());
   bk::h2d(dks, kT.data(), sizeof(int) * ns);
-  bk::block_extract(ch, Xt, m, m, d_D, dsel, dks, d_zbase, d_Z);
+  bk::block_extract(ch, Xt, m_t, m_t, d_D, dsel, dks, d_zbase, d_Z);
   bk::sync();
   if (g2) {
     double* dgs = dv(gscale.size());
     bk::h2d(dgs, gscale.data(), sizeof(double) * gscale.size());
-    bk::block_colscale(ch, Xg, m, m, dgs);
+    bk::block_colscale(ch, Xg, m_g, m_g, dgs);
     bk::h2d(dzb, zbaseG.data(), sizeof(int64_t) * (ns + 1));
     bk::h2d(dsel, selG.data(), sizeof(int) * selG.size());
     bk::h2d(dks, kG.data(), sizeof(int) * ns);
-    bk::block_extract(ch, Xg, m, m, d_D, dsel, dks, dzb, d_Z);
+    bk::block_extract(ch, Xg, m_g, m_g, d_D, dsel, dks, dzb, d_Z);
     bk::sync();
     bk::dfree(dgs);
   }
@@ -1317,6 +1435,248 @@ int PC::eigen_lobpcg() {
   bk::dfree(dsel);
   bk::dfree(dks);
   release();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ -geneo_chk
+// Diagnostics of the reference's --check mode (geneo.cpp:173-247 checkRank, :782-840 checkSPD, :988-997
+// partition of unity).  Files are written in the working directory under the reference's names;
+// the id in "check<id>" is the global subdomain id (= the MPI rank of the reference).
+static std::string check_id(int gid, int nsub) {
+  std::ostringstream w, r;
+  w << nsub;
+  r << std::setfill('0') << std::setw((int)w.str().length()) << gid;
+  return "check" + r.str();
+}
+
+// checkSPD(false, pcA, "check", "A") (geneo.cpp:1740-1743): smallest Ritz values of a Lanczos run on the
+// assembled operator (the reference asks ARPACK for the smallest-magnitude eigenvalue, then an LDLt
+// inertia that this path does not have: the inertia line says so).
+int PC::check_global_spd() {
+  const int n = n_owned();
+  const int steps = std::max(1, std::min(N, 80));
+  auto dv = [](size_t k) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, k)); };
+  double *v = dv(n), *vp = dv(n), *w = dv(n);
+  std::vector<double> h(std::max(1, n));
+  for (int i = 0; i < n; ++i) h[i] = bk::hash_unit_host(opt.eps_seed + 17, 0, (uint64_t)owned[i], 0) - 0.5;
+  bk::h2d(v, h.data(), sizeof(double) * n);
+  bk::set(vp, 0.0, n);
+  double nrm = std::sqrt(gdot(v, v));
+  bk::axpby(v, 0.0, v, 1.0 / nrm, n);
+  std::vector<double> al, be;
+  double beta = 0.0;
+  int rc = 0;
+  for (int k = 0; k < steps; ++k) {
+    if ((rc = matmult(v, w))) break;
+    const double a = gdot(w, v);
+    al.push_back(a);
+    bk::axpy(w, -a, v, n);
+    bk::axpy(w, -beta, vp, n);
+    beta = std::sqrt(gdot(w, w));
+    if (!(beta > 1e-13 * std::fabs(a))) break;   // invariant subspace: T is exact
+    be.push_back(beta);
+    bk::copy(vp, v, n);
+    bk::copy(v, w, n);
+    bk::axpby(v, 0.0, v, 1.0 / beta, n);
+  }
+  bk::dfree(v); bk::dfree(vp); bk::dfree(w);
+  if (rc) return rc;
+  const int k = (int)al.size();
+  std::vector<double> T((size_t)k * k, 0.0), ev, V;
+  for (int i = 0; i < k; ++i) {
+    T[(size_t)i * k + i] = al[i];
+    if (i + 1 < k && i < (int)be.size()) T[(size_t)i * k + i + 1] = T[(size_t)(i + 1) * k + i] = be[i];
+  }
+  dense::sym_eig(T, k, ev, V);
+  const double lmin = *std::min_element(ev.begin(), ev.end());
+  if (rank == 0) {
+    std::ofstream f("check.SPD.A.log");
+    f << "A - eigen value 0: " << lmin << std::endl;
+    f << std::endl << "A - inertia: not computed (no LDLt on the MI355X path; " << k << " Lanczos steps, largest Ritz value "
+      << *std::max_element(ev.begin(), ev.end()) << ")" << std::endl;
+  }
+  if (lmin <= DBL_EPSILON) {
+    std::ostringstream msg;
+    msg << "GenEO - check SPD: A not SPD, bad eigen value " << lmin;
+    return fail(msg.str());
+  }
+  return 0;
+}
+
+// checkSPD(true, pcBLoc, checkFile, pb + ".B") (geneo.cpp:883-886): smallest eigenvalue of the right-hand
+// matrix of each local pencil by LOBPCG on (B, I); exact inertia from a dense eigen-decomposition while
+// the subdomain is small enough.
+int PC::check_local_spd(const EigProblem& P, const HostCsr* const* hostB, bool scale_mult) {
+  const int ns = (int)subs.size();
+  // identity as the second operator of the pencil
+  std::vector<int> rp(nL + 1), col(std::max(1, nL));
+  std::vector<double> val(std::max(1, nL), 1.0);
+  for (int i = 0; i <= nL; ++i) rp[i] = i;
+  for (int i = 0; i < nL; ++i) col[i] = i;
+  bk::Csr eye = bk::csr_upload(nL, rp.data(), col.data(), val.data());
+  EigProblem Q{P.B, P.Bs, &eye, nullptr, nullptr, nullptr, 0.0, 1, P.label};
+  // Jacobi scaling and Gershgorin bound of B for the Chebyshev preconditioner
+  std::vector<double> dinv(std::max(1, nL));
+  double lmax = 0.0;
+  for (int s = 0; s < ns; ++s) {
+    const HostCsr& b = *hostB[s];
+    const std::vector<int>& mu = subs[s].mult;
+    for (int i = 0; i < b.n; ++i) {
+      double diag = 0.0, row = 0.0;
+      for (int k = b.rowptr[i]; k < b.rowptr[i + 1]; ++k) {
+        const double v = scale_mult ? b.val[k] / ((double)mu[i] * (double)mu[b.col[k]]) : b.val[k];
+        if (b.col[k] == i) diag += v;
+        row += std::fabs(v);
+      }
+      if (!(diag > 0.0)) {
+        bk::csr_free(eye);
+        std::ostringstream msg;
+        msg << "GenEO - check SPD: " << P.label << ".B not SPD, bad diagonal value " << diag;
+        return fail(msg.str());
+      }
+      dinv[suboff[s] + i] = 1.0 / diag;
+      lmax = std::max(lmax, row / diag);
+    }
+  }
+  double* d_dinv = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
+  bk::h2d(d_dinv, dinv.data(), sizeof(double) * nL);
+  Q.dinv = d_dinv;
+  Q.lmax = lmax;
+  std::vector<double> lam;
+  double* X = (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, (size_t)nL * 16));
+  const int its_before = info.eig_iterations;
+  int rc = lobpcg_solve(Q, 16, lam, X);
+  info.eig_iterations = its_before;   // diagnostics do not count as eigensolver work
+  bk::dfree(X);
+  bk::dfree(d_dinv);
+  bk::csr_free(eye);
+  if (rc) return rc;
+  for (int s = 0; s < ns; ++s) {
+    const std::string name = check_id(subs[s].gid, nsub_global) + ".SPD." + P.label + ".B.log";
+    std::ofstream f(name.c_str());
+    const double l0 = lam[(size_t)s * 16];
+    f << P.label << ".B - eigen value 0: " << l0 << std::endl;
+    const int n = (int)subs[s].l2g.size();
+    int neg = 0, nul = 0, pos = 0;
+    bool have_inertia = false;
+    if (n <= 1024) {
+      const HostCsr& b = *hostB[s];
+      std::vector<double> G((size_t)n * n, 0.0), w, V;
+      for (int i = 0; i < n; ++i)
+        for (int k = b.rowptr[i]; k < b.rowptr[i + 1]; ++k)
+          G[(size_t)i * n + b.col[k]] += scale_mult ? b.val[k] / ((double)subs[s].mult[i] * (double)subs[s].mult[b.col[k]]) : b.val[k];
+      dense::sym_eig(G, n, w, V);
+      double wmax = 0.0;
+      for (double v : w) wmax = std::max(wmax, std::fabs(v));
+      for (double v : w) {
+        if (std::fabs(v) <= 1e-14 * wmax) nul++;
+        else if (v < 0) neg++;
+        else pos++;
+      }
+      have_inertia = true;
+      f << std::endl << P.label << ".B - inertia: nbNegEV " << neg << ", nbNullEV " << nul << ", nbPosEV " << pos << std::endl;
+    } else {
+      f << std::endl << P.label << ".B - inertia: not computed (n = " << n << " > 1024, no LDLt on the MI355X path)" << std::endl;
+    }
+    if (l0 <= DBL_EPSILON) {
+      std::ostringstream msg;
+      msg << "GenEO - check SPD: " << P.label << ".B not SPD, bad eigen value " << l0;
+      return fail(msg.str());
+    }
+    if (have_inertia && (neg > 0 || nul > 0))
+      return fail("GenEO - check SPD: not SPD (inertia - negative or null eigen value found)");
+  }
+  return 0;
+}
+
+// checkRank(true, pcZE2L, ...) (geneo.cpp:280-283): Z_s = Q R by modified Gram-Schmidt with one
+// refinement pass (BV_ORTHOG_MGS + REFINE_ALWAYS, :203); every R(i,i) must be non zero.
+int PC::check_local_rank() {
+  const int ns = (int)subs.size();
+  std::vector<int64_t> zb(ns + 1);
+  bk::d2h(zb.data(), d_zbase, sizeof(int64_t) * (ns + 1));
+  for (int s = 0; s < ns; ++s) {
+    const int n = (int)subs[s].l2g.size(), k = ksub[s];
+    std::vector<double> Zs((size_t)n * k), R((size_t)k * k, 0.0);
+    bk::d2h(Zs.data(), d_Z + zb[s], sizeof(double) * (size_t)n * k);
+    for (int j = 0; j < k; ++j) {
+      double* zj = Zs.data() + (size_t)j * n;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < j; ++i) {
+          const double* qi = Zs.data() + (size_t)i * n;
+          double d = 0.0;
+          for (int t = 0; t < n; ++t) d += qi[t] * zj[t];
+          for (int t = 0; t < n; ++t) zj[t] -= d * qi[t];
+          R[(size_t)i * k + j] += d;
+        }
+      double nr = 0.0;
+      for (int t = 0; t < n; ++t) nr += zj[t] * zj[t];
+      nr = std::sqrt(nr);
+      R[(size_t)j * k + j] = nr;
+      if (nr > 0)
+        for (int t = 0; t < n; ++t) zj[t] /= nr;
+    }
+    const std::string name = check_id(subs[s].gid, nsub_global) + ".setup.Z.R";
+    std::ofstream f(name.c_str());
+    f.precision(16);
+    for (int i = 0; i < k; ++i) {
+      for (int j = 0; j < k; ++j) f << (j ? " " : "") << R[(size_t)i * k + j];
+      f << std::endl;
+    }
+    for (int i = 0; i < k; ++i)
+      if (std::fabs(R[(size_t)i * k + i]) <= DBL_EPSILON) {
+        std::ostringstream msg;
+        msg << "GenEO - check rank: Z = Q*R with R(" << i << ", " << i << ") = " << R[(size_t)i * k + i];
+        return fail(msg.str());
+      }
+  }
+  return 0;
+}
+
+// checkRank(false, pcZE2G, ...) (geneo.cpp:412-415): the global Z (N x dimE).  R is the Cholesky factor of
+// the Gram matrix Z^T Z assembled with the operators of the coarse correction (Z, R^T, R, Z^T).
+int PC::check_global_rank() {
+  std::vector<double> G((size_t)dimE * dimE, 0.0), unit(dimE, 0.0), colv(dimE);
+  for (int j = 0; j < dimE; ++j) {
+    unit[j] = 1.0;
+    bk::h2d(d_yE, unit.data(), sizeof(double) * dimE);
+    unit[j] = 0.0;
+    bk::z_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, d_yE, d_wL, false);
+    prolong_add(d_wL, d_t1);
+    restrict_to_local(d_t1, d_xL);
+    bk::zt_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, kmax, d_xL, d_yE, dimE);
+    allreduce(d_yE, dimE);
+    bk::d2h(colv.data(), d_yE, sizeof(double) * dimE);
+    for (int i = 0; i < dimE; ++i) G[(size_t)i * dimE + j] = colv[i];
+  }
+  // right-looking Cholesky G = R^T R; a non-positive pivot is reported as R(i,i) = 0
+  std::vector<double> R((size_t)dimE * dimE, 0.0);
+  int bad = -1;
+  for (int i = 0; i < dimE && bad < 0; ++i) {
+    double d = G[(size_t)i * dimE + i];
+    for (int t = 0; t < i; ++t) d -= R[(size_t)t * dimE + i] * R[(size_t)t * dimE + i];
+    if (!(d > DBL_EPSILON * DBL_EPSILON * G[(size_t)i * dimE + i])) { bad = i; break; }
+    const double rii = std::sqrt(d);
+    R[(size_t)i * dimE + i] = rii;
+    for (int j = i + 1; j < dimE; ++j) {
+      double v = 0.5 * (G[(size_t)i * dimE + j] + G[(size_t)j * dimE + i]);
+      for (int t = 0; t < i; ++t) v -= R[(size_t)t * dimE + i] * R[(size_t)t * dimE + j];
+      R[(size_t)i * dimE + j] = v / rii;
+    }
+  }
+  if (rank == 0) {
+    std::ofstream f("check.setup.ZE2G.R");
+    f.precision(16);
+    for (int i = 0; i < dimE; ++i) {
+      for (int j = 0; j < dimE; ++j) f << (j ? " " : "") << R[(size_t)i * dimE + j];
+      f << std::endl;
+    }
+  }
+  if (bad >= 0) {
+    std::ostringstream msg;
+    msg << "GenEO - check rank: Z = Q*R with R(" << bad << ", " << bad << ") = 0";
+    return fail(msg.str());
+  }
   return 0;
 }
 

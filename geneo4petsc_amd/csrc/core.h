@@ -26,6 +26,7 @@ struct Options {
   bool cst = false;
   int cut = -1;
   bool noSyl = false, offload = false;
+  bool check = false;      // -geneo_chk (geneo.cpp:2466-2479)
   // -els2_ : local eigensolver (LOBPCG on the GPU replaces ARPACK shift-invert, geneo.cpp:626-744)
   double eps_tol = 1e-3;   // EPSSetTolerances default at geneo.cpp:658
   int eps_nev = 16;        // block target when -geneo_cut is not given (no inertia count on the GPU)
@@ -167,8 +168,13 @@ class PC {
   };
   int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
   int eig_targets(int* nev_try) const;
+  int eig_block_max() const;
   void local_tau();
   int local_gamma();
+  int check_global_spd();
+  int check_local_spd(const EigProblem& P, const HostCsr* const* hostB, bool scale_mult);
+  int check_local_rank();
+  int check_global_rank();
   int eigen_dense_host();
   int eigen_lobpcg();
   int build_E();

@@ -33,7 +33,7 @@ def test_modes_match_oracle(lib, lvl, ksp, overlap):
 @pytest.mark.parametrize("lvl,ksp,n,parts,cut,inter", [("SORAS,2", "cg", 12, (3, 2, 1), 12, True),
                                                        ("ORAS,H2", "gmres", 10, (2, 2, 2), 10, False),
                                                        ("SORAS,E2", "cg", 6, (2, 2, 1), 12, False),
-                                                       ("SORAS,2", "cg", 16, (2, 2, 2), 10, False)])
+                                                       ("SORAS,2", "cg", 16, (2, 2, 2), 14, False)])
 def test_geneo2_matches_oracle(lib, lvl, ksp, n, parts, cut, inter):
     """GenEO-2 (geneo.cpp:1274-1300): tau problem on (A_Neu, A_Rob) with tau_loc and gamma problem on
     (D A_Dir D, A_Rob) with gamma_loc -- the largest eigenvalues, computed by LOBPCG on the inverted pencil."""
@@ -41,6 +41,25 @@ def test_geneo2_matches_oracle(lib, lvl, ksp, n, parts, cut, inter):
             "-ksp_type", ksp] + TIGHT
     _, info = cases.compare_with_oracle(lib, n, parts, 1, argv, with_intersect=inter)
     assert info["dimE"] > len(parts)
+
+
+def test_no_cut_keeps_every_eigenvalue_below_tau(lib):
+    """No -geneo_cut: the reference's inertia count keeps every eigenvalue below tau; the LOBPCG block grows to reach it."""
+    _, info = cases.compare_with_oracle(lib, 10, (2, 2, 2), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.42", "-ksp_type", "cg"] + TIGHT)
+    assert info["dimE"] == 276
+
+
+def test_geneo_chk_diagnostics_on_gpu(lib, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    argv = ["-geneo_lvl", "SORAS,2", "-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", "10", "-geneo_optim", "0.5",
+            "-ksp_type", "cg", "-geneo_chk", "log"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 10, (2, 2, 2), 1, argv)
+    assert float((tmp_path / "check.SPD.A.log").read_text().splitlines()[0].split(":")[1]) > 0
+    for gid in range(8):
+        assert "nbNegEV 0, nbNullEV 0, nbPosEV 290" in (tmp_path / ("check%d.SPD.gamma.B.log" % gid)).read_text()
+        r = np.loadtxt(tmp_path / ("check%d.setup.Z.R" % gid))
+        assert np.all(np.abs(np.diag(r)) > 1e-8)
+    assert np.loadtxt(tmp_path / "check.setup.ZE2G.R").shape == (info["dimE"], info["dimE"])
 
 
 def test_config0_laplacian_2d_two_subdomains_five_vectors(lib):

@@ -140,3 +140,66 @@ def test_known_answer_E_and_Qb(lib):
     assert info["nicolaidesLoc"] == 2 and info["dimE"] == 2 and list(pc.local_dims()) == [1, 1]
     np.testing.assert_allclose(pc.E(), np.diag([10.0, 8.0]), atol=1e-12)
     np.testing.assert_allclose(pc.apply_q(b), [2, 2, 2, 4.25, 6.5, 6.5, 6.5, 6.5], atol=1e-12)
+
+
+def test_geneo_chk_diagnostics(lib, tmp_path, monkeypatch):
+    """-geneo_chk (geneo.cpp:173-247, :782-840, :988-997): SPD logs of A and of each pencil's B, R of Z = QR
+    locally and globally, under the reference's file names; results unchanged by the checks."""
+    monkeypatch.chdir(tmp_path)
+    argv = ["-geneo_lvl", "SORAS,2", "-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", "10", "-geneo_optim", "0.5",
+            "-ksp_type", "cg", "-geneo_chk", "log"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 10, (2, 2, 2), 1, argv)
+    a_log = (tmp_path / "check.SPD.A.log").read_text()
+    lmin = float(a_log.splitlines()[0].split(":")[1])
+    mesh, dec, a, b = cases.grid_case(10, 3, (2, 2, 2), 1)
+    import scipy.sparse.linalg as spla
+    true_min = spla.eigsh(a, k=1, sigma=0, which="LM")[0][0]
+    assert 0 < true_min <= lmin * (1 + 1e-12) and lmin < 1.2 * true_min       # Lanczos Ritz value: upper bound, close
+    for gid in range(8):
+        for pb in ("tau", "gamma"):
+            txt = (tmp_path / ("check%d.SPD.%s.B.log" % (gid, pb))).read_text()
+            assert txt.startswith(pb + ".B - eigen value 0: ") and "nbNegEV 0, nbNullEV 0, nbPosEV 290" in txt
+        r = np.loadtxt(tmp_path / ("check%d.setup.Z.R" % gid))
+        assert r.shape[0] == r.shape[1] and np.all(np.abs(np.diag(r)) > 1e-8) and np.allclose(r, np.triu(r))
+    rg = np.loadtxt(tmp_path / "check.setup.ZE2G.R")
+    assert rg.shape == (info["dimE"], info["dimE"]) and np.all(np.diag(rg) > 0)
+    # small subdomains (dense path) write the same files
+    cases.compare_with_oracle(lib, 6, (2, 1, 1), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "4", "-geneo_chk", "log"] + TIGHT)
+    assert "nbNegEV 0, nbNullEV 0" in (tmp_path / "check1.SPD.tau.B.log").read_text()
+
+
+def test_geneo_chk_flags_a_singular_operator(lib, tmp_path, monkeypatch):
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC, GenEOError
+    monkeypatch.chdir(tmp_path)
+    d = dc.load()
+    mesh = decomp.read_input_text(d["inputs"]["tridiag.inp"], 1.0)
+    width = mesh.nodes.shape[1]
+    for k in range(len(mesh.mats)):                         # pure Neumann chain: singular A
+        if np.count_nonzero(mesh.nodes[k] >= 0) == 2:
+            m = np.zeros((width, width))
+            m[:2, :2] = [[1.0, -1.0], [-1.0, 1.0]]
+            mesh.mats[k] = m.ravel()
+        else:
+            mesh.mats[k] = 0.0
+    rec = [r for r in dc.geneo_refs() if r["file"] == "tridiag-pc=geneoASM1-metis=dual.ref"][0]
+    ep, npart = dc.partition_for(rec)
+    dec = decomp.decompose(mesh, 2, ep, npart, True, 0)
+    pc = GenEOPC(lib)
+    pc.set_from_options(["-geneo_lvl", "ASM,1", "-geneo_chk", "log"])
+    with pytest.raises(GenEOError, match="invalid option -geneo_chk, unknown foo"):
+        GenEOPC(lib).set_from_options(["-geneo_chk", "foo"])
+    pc.set_sizes(8, 2)
+    for dom in dec.domains:
+        pc.add_subdomain(dom.gid, dom.l2g, dom.mult, dom.a_neu, None)
+    with pytest.raises(GenEOError, match="GenEO - check SPD: A not SPD"):
+        pc.setup(np.ones(8))
+
+
+def test_no_cut_keeps_every_eigenvalue_below_tau(lib):
+    """Without -geneo_cut the reference's nev is the inertia count (geneo.cpp:502-560): every eigenvalue below tau
+    enters Z.  The LOBPCG block grows (16 -> 32 -> 64 columns) until the threshold falls inside it; small
+    subdomains read the count off the dense spectrum."""
+    _, info = cases.compare_with_oracle(lib, 10, (2, 2, 2), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.42", "-ksp_type", "cg"] + TIGHT)
+    assert info["dimE"] == 276
+    cases.compare_with_oracle(lib, 6, (2, 1, 1), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.3", "-ksp_type", "cg"] + TIGHT)
