@@ -37,6 +37,11 @@ class GeneoInfo(C.Structure):
                [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double)]
 
 
+class GeneoInput(C.Structure):
+    _fields_ = [("nbElem", C.c_uint), ("nbNode", C.c_uint), ("elemPtr", C.POINTER(C.c_uint)),
+                ("elemIdx", C.POINTER(C.c_uint)), ("elemMat", c_dbl_p), ("nIdx", C.c_size_t), ("nMat", C.c_size_t)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 
@@ -76,6 +81,8 @@ SYMBOLS = {
     "PCGenEOGetLocalDims": (C.c_int, [C.c_void_p, c_int_p, C.c_int]),
     "PCGenEOGetLocalParams": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p, C.c_int]),
     "PCGenEOSetIntersect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p]),
+    "GeneoGetLibInput": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GeneoInput)]),
+    "GeneoFreeInput": (None, [C.POINTER(GeneoInput)]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
     "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),

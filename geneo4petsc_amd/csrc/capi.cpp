@@ -1,5 +1,8 @@
 // extern "C" entry points of libgeneopc (declared in include/geneo_c.h).
+#include <dlfcn.h>
+
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -361,6 +364,70 @@ int PCGenEOGetLocalDims(PC pc, int* k, int cap) {
   const auto& v = pc->ctx->ksub_global;
   for (int i = 0; i < (int)v.size() && i < cap; ++i) k[i] = v[i];
   return (int)v.size();
+}
+
+// ---- getInput plugin ABI (driver:75-96) -----------------------------------------------------------
+// Loads a plugin built for the reference driver (tst/laplacian, tst/heat, tst/graph or a user's own) and
+// flattens what it returns.  The C++ signature is the plugin contract itself (driver:81-85).
+typedef int (*geneo_get_input_fn)(std::string const& args, unsigned int& nbElem, unsigned int& nbNode,
+                                  std::vector<unsigned int>& elemPtr, std::vector<unsigned int>& elemIdx,
+                                  std::vector<std::vector<double>>& elemSubMat);
+PetscErrorCode GeneoGetLibInput(const char* inpLibA, const char* inpLibArg, GeneoInput* out) {
+  if (!inpLibA || !out) return 1;
+  memset(out, 0, sizeof(*out));
+  void* lib = dlopen(inpLibA, RTLD_LAZY | RTLD_LOCAL);
+  if (!lib) {
+    g_global_err = std::string("Error: open library KO - ") + dlerror();
+    return 1;
+  }
+  geneo_get_input_fn fn = (geneo_get_input_fn)dlsym(lib, "getInput");
+  if (!fn) {
+    g_global_err = std::string("Error: get input function from library KO - ") + dlerror();
+    dlclose(lib);
+    return 1;
+  }
+  std::string args = inpLibArg ? inpLibArg : "";
+  for (auto& c : args)
+    if (c == '#') c = ' ';
+  unsigned int ne = 0, nn = 0;
+  std::vector<unsigned int> ptr, idx;
+  std::vector<std::vector<double>> sub;
+  int rc = 1;
+  try {
+    rc = fn(args, ne, nn, ptr, idx, sub);
+  } catch (std::exception& e) {
+    g_global_err = e.what();
+  }
+  if (rc != 0 || ptr.size() != (size_t)ne + 1 || sub.size() != ne) {
+    if (g_global_err.empty() || rc != 0) g_global_err = "Error: get input data from library KO";
+    dlclose(lib);
+    return 1;
+  }
+  size_t tot = 0;
+  for (auto& m : sub) tot += m.size();
+  out->nbElem = ne;
+  out->nbNode = nn;
+  out->nIdx = idx.size();
+  out->nMat = tot;
+  out->elemPtr = (unsigned int*)malloc(sizeof(unsigned int) * (ptr.size() + 1));
+  out->elemIdx = (unsigned int*)malloc(sizeof(unsigned int) * (idx.size() + 1));
+  out->elemMat = (double*)malloc(sizeof(double) * (tot + 1));
+  memcpy(out->elemPtr, ptr.data(), sizeof(unsigned int) * ptr.size());
+  memcpy(out->elemIdx, idx.data(), sizeof(unsigned int) * idx.size());
+  size_t pos = 0;
+  for (auto& m : sub) {
+    memcpy(out->elemMat + pos, m.data(), sizeof(double) * m.size());
+    pos += m.size();
+  }
+  dlclose(lib);
+  return 0;
+}
+void GeneoFreeInput(GeneoInput* in) {
+  if (!in) return;
+  free(in->elemPtr);
+  free(in->elemIdx);
+  free(in->elemMat);
+  memset(in, 0, sizeof(*in));
 }
 
 // ---- device helpers ------------------------------------------------------------------------

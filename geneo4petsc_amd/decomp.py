@@ -51,6 +51,38 @@ def mesh_from_lists(nb_node, elem_ptr, elem_idx, elem_mats) -> ElementMesh:
     return ElementMesh(nb_node, nodes, mats)
 
 
+def plugin_mesh(lib, path: str, args: str) -> ElementMesh:
+    """--inpLibA with a real `getInput` plugin (.so built for the reference driver, driver:75-96), loaded through
+    the C ABI (GeneoGetLibInput)."""
+    import ctypes as C
+    from . import _lib as L
+    inp = L.GeneoInput()
+    if lib.GeneoGetLibInput(path.encode(), args.encode(), C.byref(inp)):
+        raise RuntimeError(lib.PCGenEOGetError(None).decode() or "Error: get input data from library KO")
+    try:
+        ne = inp.nbElem
+        ptr = np.ctypeslib.as_array(inp.elemPtr, shape=(ne + 1,)).astype(np.int64)
+        idx = np.ctypeslib.as_array(inp.elemIdx, shape=(max(1, inp.nIdx),))[:inp.nIdx].astype(np.int64)
+        val = np.ctypeslib.as_array(inp.elemMat, shape=(max(1, inp.nMat),))[:inp.nMat].copy()
+        k = np.diff(ptr)
+        w = int(k.max())
+        nodes = -np.ones((ne, w), dtype=np.int64)
+        mats = np.zeros((ne, w * w))
+        moff = np.concatenate([[0], np.cumsum(k * k)])
+        if np.all(k == w):                      # uniform elements (all three reference generators): vectorised
+            nodes[:] = idx.reshape(ne, w)
+            mats[:] = val.reshape(ne, w * w)
+        else:
+            for e in range(ne):
+                nodes[e, :k[e]] = idx[ptr[e]:ptr[e + 1]]
+                blk = np.zeros((w, w))
+                blk[:k[e], :k[e]] = val[moff[e]:moff[e + 1]].reshape(k[e], k[e])
+                mats[e] = blk.ravel()
+        return ElementMesh(int(inp.nbNode), nodes, mats)
+    finally:
+        lib.GeneoFreeInput(C.byref(inp))
+
+
 def read_input_text(text: str, inp_eps: float = 1e-4) -> ElementMesh:
     """--inpFileA element list: 'dof dof ... [- a11 a12 ...]', '#'/'%' comments (driver:98-194)."""
     ptr, idx, mats = [0], [], []
@@ -236,6 +268,161 @@ def structured_node_partition(n, dim, parts_xyz):
 def graph_node_partition(mesh: ElementMesh, nb_part: int):
     """Greedy BFS-free splitter for unstructured inputs: contiguous node-id ranges of equal size."""
     return (np.arange(mesh.nbNode) * nb_part // mesh.nbNode).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------- k-way partitioner
+def mesh_graph(mesh: ElementMesh, dual: bool) -> sp.csr_matrix:
+    """The graph Metis partitions (driver:381-445): dual = elements adjacent when they share >= ncommon = 1 node
+    (METIS_PartMeshDual, driver:386-413), nodal = nodes adjacent when they share an element (METIS_PartMeshNodal)."""
+    e, w = np.nonzero(mesh.nodes >= 0)
+    inc = sp.csr_matrix((np.ones(len(e), dtype=np.int8), (e, mesh.nodes[e, w])), shape=(mesh.nbElem, mesh.nbNode))
+    g = (inc @ inc.T) if dual else (inc.T @ inc)
+    g = g.tocsr()
+    g.setdiag(0)
+    g.eliminate_zeros()
+    g.data[:] = 1
+    return g
+
+
+def _bfs_order(g: sp.csr_matrix, nodes: np.ndarray) -> np.ndarray:
+    """Level-structure order of the sub-graph `nodes`, rooted at a pseudo-peripheral node (George & Liu);
+    further components are appended in the same way."""
+    from scipy.sparse.csgraph import breadth_first_order
+    sub = g[nodes][:, nodes]
+    n = len(nodes)
+    seen = np.zeros(n, dtype=bool)
+    out = []
+    while len(out) < n:
+        root = int(np.flatnonzero(~seen)[0])
+        for _ in range(3):                       # walk to the far end of the component
+            order = breadth_first_order(sub, root, directed=False, return_predecessors=False)
+            if order[-1] == root:
+                break
+            root = int(order[-1])
+        order = breadth_first_order(sub, root, directed=False, return_predecessors=False)
+        seen[order] = True
+        out.extend(order.tolist())
+    return nodes[np.asarray(out, dtype=np.int64)]
+
+
+def _refine_bisection(g: sp.csr_matrix, nodes: np.ndarray, side: np.ndarray, passes: int = 4) -> np.ndarray:
+    """Boundary smoothing of a bisection: swap equal numbers of vertices whose move lowers the edge cut
+    (gain = external - internal degree), best gains first; sizes stay exact."""
+    sub = g[nodes][:, nodes].tocsr()
+    for _ in range(passes):
+        s = side.astype(np.float64)
+        to_b = sub @ s                           # neighbours in B
+        deg = np.asarray(sub.sum(axis=1)).ravel()
+        gain = np.where(side, (deg - to_b) - to_b, to_b - (deg - to_b))   # external - internal
+        a_c = np.flatnonzero((~side) & (gain > 0))
+        b_c = np.flatnonzero(side & (gain > 0))
+        k = min(len(a_c), len(b_c))
+        if k == 0:
+            break
+        a_c = a_c[np.argsort(-gain[a_c], kind="stable")][:k]
+        b_c = b_c[np.argsort(-gain[b_c], kind="stable")][:k]
+        # moving adjacent vertices together invalidates their gains: keep an independent set
+        pick = np.zeros(len(nodes), dtype=bool)
+        blocked = np.zeros(len(nodes), dtype=bool)
+        take_a, take_b = [], []
+        for va, vb in zip(a_c, b_c):
+            if blocked[va] or blocked[vb]:
+                continue
+            take_a.append(va); take_b.append(vb)
+            for v in (va, vb):
+                pick[v] = True
+                blocked[v] = True
+                blocked[sub.indices[sub.indptr[v]:sub.indptr[v + 1]]] = True
+        if not take_a:
+            break
+        side = side.copy()
+        side[take_a] = True
+        side[take_b] = False
+    return side
+
+
+def partition_graph(g: sp.csr_matrix, nb_part: int, refine: bool = True) -> np.ndarray:
+    """Deterministic k-way partition by recursive level-structure bisection + boundary smoothing: the bisections
+    are balanced to one vertex; absorbing stray fragments afterwards may shift a few vertices (a few % at most,
+    Metis' own default tolerance is 3 %).  Every part is non-empty (nb_part <= n).  Stands in for METIS_PartMeshDual/Nodal
+    (driver:381-445), which is not available offline; a Metis .part file can be given instead (--partFile)."""
+    n = g.shape[0]
+    if nb_part > n:
+        raise ValueError("more parts than vertices")
+    part = np.zeros(n, dtype=np.int64)
+    stack = [(np.arange(n, dtype=np.int64), 0, nb_part)]
+    while stack:
+        nodes, first, k = stack.pop()
+        if k == 1:
+            part[nodes] = first
+            continue
+        k1 = k // 2
+        n1 = (len(nodes) * k1 + k // 2) // k
+        n1 = min(max(n1, k1), len(nodes) - (k - k1))
+        order = _bfs_order(g, nodes)
+        side = np.zeros(len(nodes), dtype=bool)          # False = A (first n1 of the level structure)
+        pos = np.empty(len(nodes), dtype=np.int64)
+        lookup = {int(v): i for i, v in enumerate(nodes)} if len(nodes) < 64 else None
+        if lookup is None:
+            inv = np.full(n, -1, dtype=np.int64)
+            inv[nodes] = np.arange(len(nodes))
+            pos = inv[order]
+        else:
+            pos = np.array([lookup[int(v)] for v in order], dtype=np.int64)
+        side[pos[n1:]] = True
+        if refine and len(nodes) > 8:
+            from scipy.sparse.csgraph import connected_components
+            ncomp = lambda sd: sum(connected_components(g[nodes[m]][:, nodes[m]])[0] for m in (sd, ~sd))
+            better = _refine_bisection(g, nodes, side)
+            if ncomp(better) <= ncomp(side):             # smoothing must not tear a part into pieces
+                side = better
+        stack.append((nodes[~side], first, k1))
+        stack.append((nodes[side], first + k1, k - k1))
+    return _absorb_fragments(g, part, nb_part) if refine else part
+
+
+def _absorb_fragments(g: sp.csr_matrix, part: np.ndarray, nb_part: int) -> np.ndarray:
+    """Mid-level cuts can leave a few stray vertices cut off from their part.  Hand each stray fragment to the
+    neighbouring part it touches most and take the same number of boundary vertices back, so that the sizes
+    stay put.  (Like Metis without METIS_OPTION_CONTIG, contiguity is an aim, not a guarantee.)"""
+    from scipy.sparse.csgraph import connected_components
+    part = part.copy()
+    for q in range(nb_part):
+        idx = np.flatnonzero(part == q)
+        nc, lab = connected_components(g[idx][:, idx])
+        if nc == 1:
+            continue
+        main = int(np.argmax(np.bincount(lab)))
+        for c in range(nc):
+            if c == main:
+                continue
+            frag = idx[lab == c]
+            nb = g[frag].indices
+            nb = nb[part[nb] != q]
+            if len(nb) == 0:
+                continue                                   # a genuinely separate component of the graph
+            dest = int(np.bincount(part[nb], minlength=nb_part).argmax())
+            part[frag] = dest
+            # take len(frag) vertices of dest back: those touching q's main body, most q-neighbours first
+            is_q = (part == q).astype(np.int32)
+            cand = np.flatnonzero(part == dest)
+            cand = cand[~np.isin(cand, frag)]
+            touch = np.asarray(g[cand] @ is_q).ravel()
+            order = cand[np.argsort(-touch, kind="stable")]
+            order = order[: len(frag)]
+            part[order[touch[np.argsort(-touch, kind="stable")][: len(frag)] > 0]] = q
+    return part
+
+
+def partition_mesh(mesh: ElementMesh, nb_part: int, dual: bool):
+    """(elem_part, node_part) as `decompose` takes them: dual partitions the elements, nodal the nodes."""
+    p = partition_graph(mesh_graph(mesh, dual), nb_part)
+    return (p, None) if dual else (None, p)
+
+
+def edge_cut(g: sp.csr_matrix, part: np.ndarray) -> int:
+    coo = g.tocoo()
+    return int(np.count_nonzero(part[coo.row] != part[coo.col]) // 2)
 
 
 # ------------------------------------------------------------------------------- decomposition

@@ -8,7 +8,8 @@ reference generators by name: laplacian | heat | graph, arguments '#'-separated 
 --inpFileB, --inpEps, --metisDual / --metisNodal, --addOverlap, --verbose, --timing, --shortRes, --cmdLine;
 PETSc-style options (-geneo_*, -ksp_*, -els2_*, -dls1_*) are forwarded to the PC.  `--np N` stands for
 `mpirun -n N` (number of subdomains); the partition comes from `--parts px,py,pz` (structured block
-splitter), `--partFile` (one part id per line: a Metis .part file) or contiguous node ranges.
+splitter), `--partFile` (one part id per line: a Metis .part file) or, by default, the built-in k-way
+partitioner of decomp.partition_mesh on the dual (--metisDual) or nodal (--metisNodal) graph.
 
 Output: the reference's INFO: / TIME: lines in the shapes tst/plot.py:57-116 parses
 (printIterativeGlobalSolveParameters/Results/Timing, driver:898-1231).
@@ -54,11 +55,17 @@ def parse_cli(argv):
     return o
 
 
-def load_mesh(o):
-    """--inpFileA / --inpLibA (driver:144-194, :75-96)."""
+def load_mesh(o, lib=None):
+    """--inpFileA / --inpLibA (driver:144-194, :75-96).  --inpLibA takes either the path of a `getInput` plugin
+    built for the reference driver (loaded unchanged through GeneoGetLibInput) or the bare name of one of the
+    three reference generators restated in decomp.py (laplacian | heat | graph)."""
+    import os
     if o["inpFileA"]:
         return decomp.read_input_text(open(o["inpFileA"]).read(), o["inpEps"]), None
     name, _, rest = o["inpLibA"].partition("#")
+    if os.path.isfile(name):
+        from . import _lib
+        return decomp.plugin_mesh(lib if lib is not None else _lib.load(), name, rest), None
     name = name.split("/")[-1].replace("lib", "").replace(".so", "")
     tok = rest.replace("#", " ").split()
     kw = {}
@@ -89,12 +96,10 @@ def make_partition(o, mesh, grid):
     if o["partFile"]:
         part = np.loadtxt(o["partFile"], dtype=np.int64).reshape(-1)
         return (part, None) if o["metisDual"] else (None, part)
-    if o["metisDual"]:
-        # element partition: contiguous element ranges (Metis is not available offline)
-        return (np.arange(mesh.nbElem) * nb // mesh.nbElem).astype(np.int64), None
-    if grid is not None and o["parts"] is not None:
+    if not o["metisDual"] and grid is not None and o["parts"] is not None:
         return None, decomp.structured_node_partition(grid[0], grid[1], o["parts"])
-    return None, decomp.graph_node_partition(mesh, nb)
+    # Metis is not available offline: built-in k-way partitioner on the same dual / nodal graph (driver:381-445)
+    return decomp.partition_mesh(mesh, nb, o["metisDual"])
 
 
 def info_lines(o, mesh, nnz, pc, info, ksp, its, rnorm, reason, res_rel, nb_part):
@@ -159,7 +164,7 @@ def run(argv, lib=None, out=None):
     out = out if out is not None else sys.stdout
     o = parse_cli(argv)
     t0 = time.perf_counter()
-    mesh, grid = load_mesh(o)
+    mesh, grid = load_mesh(o, lib)
     t_read = time.perf_counter() - t0
     t0 = time.perf_counter()
     ep, npart = make_partition(o, mesh, grid)

@@ -153,6 +153,22 @@ int PCGenEOGetLocalDims(PC pc, int* ksub_global, int cap);
 /* tau_loc / gamma_loc per local subdomain (getLocalGenEOTau / Gamma, src/geneo.cpp:1097-1232); returns the count */
 int PCGenEOGetLocalParams(PC pc, double* tau_loc, double* gamma_loc, int cap);
 
+/* ---- input plugins ------------------------------------------------------------------------------
+ * The reference driver loads its operators from `--inpLibA lib.so#args` plugins exporting the C++ function
+ * `getInput` (src/geneo4PETSc.cpp:75-96; tst/laplacian, tst/heat, tst/graph).  GeneoGetLibInput loads such a
+ * plugin unchanged ('#' in the arguments stands for a blank, as on the reference CLI) and returns the element
+ * list flattened: element e has nodes elemIdx[elemPtr[e] .. elemPtr[e+1]) and a row-major k x k matrix, the
+ * matrices stored back to back in elemMat.  Free with GeneoFreeInput. */
+typedef struct {
+  unsigned int nbElem, nbNode;
+  unsigned int* elemPtr;   /* nbElem + 1 */
+  unsigned int* elemIdx;   /* nIdx */
+  double* elemMat;         /* nMat */
+  size_t nIdx, nMat;
+} GeneoInput;
+PetscErrorCode GeneoGetLibInput(const char* inpLibA, const char* inpLibArg, GeneoInput* out);
+void GeneoFreeInput(GeneoInput* in);
+
 /* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
 const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */
 PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to this stream */

@@ -20,7 +20,7 @@ def build(force=False):
         [os.path.join(ROOT, "include", "geneo_c.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I", CSRC, "-o", OUT] + srcs
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wl,-Bsymbolic", "-I", CSRC, "-o", OUT] + srcs + ["-ldl"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -2,6 +2,7 @@
 restatement of the reference driver and against the reference's tst/dummy goldens."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import dummy_cases as dc
 from geneo4petsc_amd import decomp
@@ -100,3 +101,40 @@ def test_rank_plans_cover_every_halo():
     s01 = plans[0].owned[plans[0].send_idx[plans[0].send_counts[:1].sum():plans[0].send_counts[:2].sum()]]
     r10 = plans[1].halo_gid[:plans[1].recv_counts[0]]
     assert (s01 == r10).all()
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("n,k", [(10, 8), (9, 5)])
+def test_kway_partitioner(n, k, dual):
+    """Stand-in for METIS_PartMeshDual / Nodal (driver:381-445): balanced within 5 %, connected parts,
+    deterministic, cut within 2.5x of the structured blocks on a cube."""
+    from scipy.sparse.csgraph import connected_components
+    mesh = decomp.grid_mesh(size=n, dim=3)
+    g = decomp.mesh_graph(mesh, dual)
+    assert g.shape[0] == (mesh.nbElem if dual else mesh.nbNode) and (g != g.T).nnz == 0
+    p = decomp.partition_graph(g, k)
+    sizes = np.bincount(p, minlength=k)
+    assert sizes.min() >= 1 and sizes.max() - sizes.min() <= max(1, 0.05 * g.shape[0] / k * 2)
+    for q in range(k):
+        assert connected_components(g[p == q][:, p == q])[0] == 1
+    assert np.array_equal(p, decomp.partition_graph(g, k))
+    if not dual and k == 8:
+        blocks = decomp.structured_node_partition(n, 3, (2, 2, 2))
+        assert decomp.edge_cut(g, p) <= 2.5 * decomp.edge_cut(g, blocks)
+    ep, npart = decomp.partition_mesh(mesh, k, dual)
+    dec = decomp.decompose(mesh, k, ep, npart, dual, 1)
+    assert len(dec.domains) == k and all(len(d.l2g) > 0 for d in dec.domains)
+    a = decomp.global_matrix(mesh)                        # the MATIS of the decomposition assembles back to A
+    acc = sp.csr_matrix(a.shape)
+    for d in dec.domains:
+        r = sp.csr_matrix((np.ones(len(d.l2g)), (np.arange(len(d.l2g)), d.l2g)), shape=(len(d.l2g), a.shape[0]))
+        acc = acc + r.T @ d.a_neu @ r
+    assert abs(acc - a).max() < 1e-12
+
+
+def test_partitioner_handles_disconnected_and_tiny_graphs():
+    g = sp.block_diag([sp.csr_matrix(np.ones((3, 3)) - np.eye(3)), sp.csr_matrix(np.ones((4, 4)) - np.eye(4))]).tocsr()
+    p = decomp.partition_graph(g, 3)
+    assert sorted(np.bincount(p).tolist()) == [2, 2, 3]
+    with pytest.raises(ValueError):
+        decomp.partition_graph(g, 8)

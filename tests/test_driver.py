@@ -50,3 +50,29 @@ def test_full_lines_parse_like_plot_py():
     for pos in (3, 8, 12, 17, 21, 24):                          # plot.py:100-105
         float(t[pos].replace(",", ""))
     assert re.match(r"^      L1       setup: Minv \d+\.\d{5} s$", [l for l in lines if "L1       setup" in l][0])
+
+
+def test_inp_lib_plugin_abi(tmp_path):
+    """--inpLibA with a real getInput plugin (driver:75-96): the reference's own generator .so files, compiled
+    from /root/reference into oracle/_ref (test infrastructure), load unchanged through GeneoGetLibInput."""
+    import pytest
+    from oracle import ref_generators as rg
+    from geneo4petsc_amd import decomp
+    if not rg.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    lib = hu.hostsim_lib()
+    for name, args, kw in (("laplacian", "--size#6#--dim#3#--kappa#10#lin", dict(size=6, dim=3, kappa_max=10.0, interp="lin")),
+                           ("heat", "--size#5#--dim#2", dict(size=5, dim=2, heat=True)),
+                           ("graph", "--size#30#--level#2#--noGround", None)):
+        path = os.path.join(rg.REF_DIR, "lib%s.so" % name)
+        m = decomp.plugin_mesh(lib, path, args)
+        ours = decomp.graph_mesh(size=30, level=2, no_ground=True) if kw is None else decomp.grid_mesh(**kw)
+        assert m.nbNode == ours.nbNode and np.array_equal(m.nodes, ours.nodes)
+        np.testing.assert_allclose(m.mats, ours.mats, rtol=1e-15, atol=0)
+    with pytest.raises(RuntimeError, match="open library KO|get input"):
+        decomp.plugin_mesh(lib, str(tmp_path / "missing.so"), "")
+    path = os.path.join(rg.REF_DIR, "liblaplacian.so")
+    lines, x = driver.run(["--inpLibA", path + "#--size#8#--dim#3", "--np", "8", "--metisNodal", "--addOverlap", "1",
+                           "-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "4", "-ksp_type", "cg"],
+                          lib=lib, out=io.StringIO())
+    assert lines[0].startswith("INFO: nb DOFs 512, nb elements 1408,") and "converged" in lines[-1]
