@@ -329,6 +329,7 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
       L.b = (double*)bk::alloc(blk);
       L.x = (double*)bk::alloc(blk);
     }
+    L.fused = bk::csr_fusable(L.A) && (l + 1 == (int)levels.size() || bk::csr_fusable(L.P)) && !getenv("GENEO_AMG_UNFUSED");
     if (l == 0) nnz0 = (double)H.A.val.size();
     nnzt += (double)H.A.val.size();
     lv.push_back(L);
@@ -382,6 +383,18 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
   Lvl& L = lv[l];
   if (l == (int)lv.size() - 1) {
     bk::dense_sym_apply(cch, d_inv, d_invbase, B, ldb, X, ldx, m);
+    return;
+  }
+  Lvl& C0 = lv[l + 1];
+  if (prm.smooth_degree <= 1 && L.fused) {
+    // damped-Jacobi V-cycle in 4 launches per level: the vector passes ride on the SpMV / SpMM epilogues
+    const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
+    const double w = 1.0 / (0.5 * (lmax + lmin));
+    bk::spmm_fused(L.A, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
+    applyA(L.R, L.r, m, C0.b, m, m);                                                      // restrict
+    cycle(l + 1, C0.b, m, C0.x, m, m);
+    bk::spmm_fused(L.P, bk::EPI_ADD, C0.x, m, L.d, m, m, nullptr, 0, X, ldx, nullptr, 0.0);  // t = x + P e
+    bk::spmm_fused(L.A, bk::EPI_JAC, L.d, m, X, ldx, m, B, ldb, nullptr, 0, L.dinv, w);   // x = t + w D^-1 (b - A t)
     return;
   }
   smooth(L, B, ldb, X, ldx, m, true);                                      // pre-smoothing, zero guess

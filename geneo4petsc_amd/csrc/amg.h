@@ -54,6 +54,7 @@ class AmgDevice {
     int n = 0;
     double rho = 2.0;
     bool own_A = true;
+    bool fused = false;       // A and P have no long-row remainder: fused-epilogue cycle
   };
   std::vector<Lvl> lv;
   bk::Chunks cch;              // chunks of the coarsest level (per subdomain)

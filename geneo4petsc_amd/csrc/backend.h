@@ -48,6 +48,8 @@ struct Csr {
   int* long_rows = nullptr;    // rows handled by the long-row kernel
   int nlong = 0;
   int64_t sl_nnz = 0;          // stored entries incl. padding
+  int vec_lpr = 0;             // > 0: long / ragged rows (restriction, coarse Galerkin operators): the SpMV runs the
+                               // lanes-per-row CSR kernel with this many lanes per row instead of the slices
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 void csr_free(Csr& a);
@@ -59,6 +61,16 @@ void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, l
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post);
+// Fused epilogues of the multigrid cycle (one launch instead of SpMV + 1-2 vector kernels); blocks are
+// row-major with m columns, m = 1 runs the sliced SpMV kernel.  A must be square for JAC / PRE.
+//   EPI_RES : Y = B - A X
+//   EPI_ADD : Y = Z + A X                         (prolongation + correction; Y must not alias Z or X)
+//   EPI_JAC : Y = X + w dinv .* (B - A X)         (damped-Jacobi sweep, out of place)
+//   EPI_PRE : Z = w dinv .* B ;  Y = B - A Z      (zero-guess sweep + residual; X unused)
+enum { EPI_NONE = 0, EPI_RES = 1, EPI_ADD = 2, EPI_JAC = 3, EPI_PRE = 4 };
+bool csr_fusable(const Csr& a);   // no long-row remainder and the sliced layout is in use
+void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
+                double* Z, int ldz, const double* dinv, double w);
 void csr_diag(const Csr& a, double* diag);
 
 // ---- index kernels -------------------------------------------------------------------------
@@ -145,6 +157,15 @@ void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int*
 // wL[i] (+)= sum_j Z_s[j][i] * yE[zoff[s]+j]
 void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
              const double* yE, double* wL, bool accumulate);
+
+// ---- HIP graphs -------------------------------------------------------------------------------
+// Launch-bound inner loops (one inner PCG chunk = ~70 small kernels) are captured once and replayed.
+// Between begin and end every backend launch is recorded instead of executed: no allocation, copy to
+// the host or synchronisation may happen in between.
+bool  graph_capture_begin();          // false: capture unavailable (the caller runs the launches directly)
+void* graph_capture_end();            // executable graph (nullptr on failure)
+void  graph_launch(void* exec);
+void  graph_destroy(void* exec);
 
 // ---- misc -------------------------------------------------------------------------------------
 void  set_spmv_kind(int kind);  // 0: LDS row-block kernel, 1: 64-row sliced kernel (default)

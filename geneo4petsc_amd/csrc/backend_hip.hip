@@ -79,6 +79,39 @@ void zero(void* d, size_t bytes) {
   HIPCHK(hipMemsetAsync(d, 0, bytes, g_stream));
 }
 
+// ---- HIP graphs: capture on a private stream, replay on the launch stream ----------------------------
+static hipStream_t g_capture_stream = nullptr, g_saved_stream = nullptr;
+static bool g_capturing = false;
+bool graph_capture_begin() {
+  if (g_capturing || getenv("GENEO_NO_GRAPH")) return false;
+  if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {
+    g_capture_stream = nullptr;
+    return false;
+  }
+  HIPCHK(hipStreamSynchronize(g_stream));
+  if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  g_saved_stream = g_stream;
+  g_stream = g_capture_stream;
+  g_capturing = true;
+  return true;
+}
+void* graph_capture_end() {
+  if (!g_capturing) return nullptr;
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(g_capture_stream, &graph);
+  g_stream = g_saved_stream;
+  g_capturing = false;
+  if (e != hipSuccess || !graph) return nullptr;
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  return e2 == hipSuccess ? (void*)exec : nullptr;
+}
+void graph_launch(void* exec) { HIPCHK(hipGraphLaunch((hipGraphExec_t)exec, g_stream)); }
+void graph_destroy(void* exec) {
+  if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int grid1d(int64_t n, int per_block) {
   int g = cdiv(n, per_block);
@@ -102,23 +135,24 @@ __device__ __forceinline__ double block_sum_256(double v, double* sm /*>=4*/) {
 constexpr int SPMV_TILE = 1792;  // nnz staged in LDS per workgroup (14 KB): 256 rows x 7 nnz
 constexpr int SPMV_ROWS = 256;   // rows per row block (one row per thread in the reduce phase)
 constexpr int SELL_LONG = 64;    // rows longer than this bypass the sliced layout
+constexpr int SELL_VEC_MAX_ROWS = 1 << 18;   // ragged matrices below this size run the lanes-per-row kernel instead
 
 // device-side construction of the sliced layout from the CSR arrays already in HBM
-__global__ void k_slice_width(const int* __restrict__ rowptr, int n, int ns, int* __restrict__ w) {
+__global__ void k_slice_width(const int* __restrict__ rowptr, int n, int ns, int* __restrict__ w, int long_len) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   int m = 0;
   const int r1 = (64 * s + 64 < n) ? 64 * s + 64 : n;
   for (int i = 64 * s; i < r1; ++i) {
     const int len = rowptr[i + 1] - rowptr[i];
-    if (len <= SELL_LONG && len > m) m = len;
+    if (len <= long_len && len > m) m = len;
   }
   w[s] = m;
 }
 __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const double* __restrict__ val, int n, int ns,
                                                    const int64_t* __restrict__ sl_ptr, int* __restrict__ sl_col,
-                                                   double* __restrict__ sl_val) {
+                                                   double* __restrict__ sl_val, int long_len) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= ns) return;
   const int l = threadIdx.x & 63;
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
     a = rowptr[i];
     len = rowptr[i + 1] - a;
   }
-  const bool use = (i < n) && len <= SELL_LONG;
+  const bool use = (i < n) && len <= long_len;
   const int padc = (i < n && len > 0) ? col[a] : 0;
   for (int k = 0; k < w; ++k) {
     const int64_t e = base + (int64_t)64 * k + l;
@@ -158,10 +192,11 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
   int maxrow = 0;
   std::vector<int> longr;
+  const int long_len = SELL_LONG;
   for (int i = 0; i < n; ++i) {
     const int len = h_rowptr[i + 1] - h_rowptr[i];
     maxrow = std::max(maxrow, len);
-    if (len > SELL_LONG) longr.push_back(i);
+    if (len > long_len) longr.push_back(i);
   }
   a.max_row = maxrow;
   if (spmv_kind() == 0) {
@@ -192,7 +227,7 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
     const int ns = (n + 63) / 64;
     int* dw = (int*)alloc(sizeof(int) * std::max(1, ns));
     if (ns > 0)
-      hipLaunchKernelGGL(k_slice_width, dim3(grid1d(ns, 256)), dim3(256), 0, g_stream, a.rowptr, n, ns, dw);
+      hipLaunchKernelGGL(k_slice_width, dim3(grid1d(ns, 256)), dim3(256), 0, g_stream, a.rowptr, n, ns, dw, long_len);
     std::vector<int> w(std::max(1, ns));
     d2h(w.data(), dw, sizeof(int) * ns);
     dfree(dw);
@@ -206,8 +241,12 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
     h2d(a.sl_ptr, sp.data(), sizeof(int64_t) * (ns + 1));
     if (ns > 0)
       hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, g_stream, a.rowptr, a.col, a.val, n, ns,
-                         a.sl_ptr, a.sl_col, a.sl_val);
+                         a.sl_ptr, a.sl_col, a.sl_val, long_len);
     a.nlong = (int)longr.size();
+    // Long or ragged rows (restriction operators, coarse Galerkin matrices): one lane group per row reads the
+    // row coalesced and reduces with shuffles; the slices would pad every 64-row slice to its longest row.
+    const double avg = n > 0 ? (double)a.nnz / n : 0.0;
+    if (n < SELL_VEC_MAX_ROWS && (a.nlong > 0 || avg >= 20.0)) a.vec_lpr = avg <= 24.0 ? 16 : (avg <= 48.0 ? 32 : 64);
     a.long_rows = (int*)alloc(sizeof(int) * std::max<size_t>(1, longr.size()));
     h2d(a.long_rows, longr.data(), sizeof(int) * longr.size());
   }
@@ -306,6 +345,105 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ s
   const int r = 64 * s + l;
   if (r < n) y[r] = sum;
 }
+// Same traversal with the multigrid epilogues of backend.h fused in (EPI_RES / ADD / JAC / PRE): the vector
+// passes that used to follow the SpMV (residual, correction, Jacobi update) ride on its output write.
+template <bool NT, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict__ sl_ptr, int nslice, int n,
+                                                       const int* __restrict__ col, const double* __restrict__ val,
+                                                       const double* __restrict__ x, double* __restrict__ y,
+                                                       const double* __restrict__ b, double* __restrict__ z,
+                                                       const double* __restrict__ dinv, double w) {
+  constexpr int UNR = 4;
+  const int nwb = (nslice + 3) >> 2;
+  const int t = xcd_remap(blockIdx.x, nwb);
+  const int s = 4 * t + (threadIdx.x >> 6);
+  if (t >= nwb || s >= nslice) return;
+  const int l = threadIdx.x & 63;
+  const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
+  double acc[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
+  int64_t e = a + l;
+  for (; e + 64 * (UNR - 1) < e1; e += 64 * UNR) {
+    int c[UNR];
+    double v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      c[u] = NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u];
+      v[u] = NT ? __builtin_nontemporal_load(val + e + 64 * u) : val[e + 64 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc[u] += v[u] * (EPI == EPI_PRE ? b[c[u]] * dinv[c[u]] : x[c[u]]);
+  }
+  for (; e < e1; e += 64) {
+    const int c0 = NT ? __builtin_nontemporal_load(col + e) : col[e];
+    const double v0 = NT ? __builtin_nontemporal_load(val + e) : val[e];
+    acc[0] += v0 * (EPI == EPI_PRE ? b[c0] * dinv[c0] : x[c0]);
+  }
+  double sum = acc[0];
+#pragma unroll
+  for (int u = 1; u < UNR; ++u) sum += acc[u];
+  const int r = 64 * s + l;
+  if (r >= n) return;
+  if (EPI == EPI_RES) {
+    y[r] = b[r] - sum;
+  } else if (EPI == EPI_ADD) {
+    y[r] = z[r] + sum;
+  } else if (EPI == EPI_JAC) {
+    y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else {  // EPI_PRE
+    const double bb = b[r];
+    z[r] = w * dinv[r] * bb;
+    y[r] = bb - w * sum;
+  }
+}
+// Lanes-per-row CSR kernel for long / ragged rows, with the same epilogues: LPR lanes stride over one row
+// (coalesced col/val reads), partial sums are combined by a fixed butterfly, lane 0 writes.
+template <int LPR, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_vec(int n, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                  const double* __restrict__ val, const double* __restrict__ x,
+                                                  double* __restrict__ y, const double* __restrict__ b,
+                                                  double* __restrict__ z, const double* __restrict__ dinv, double w) {
+  constexpr int RPB = 256 / LPR;
+  const int lane = threadIdx.x % LPR;
+  const int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = r < n;
+  double s = 0.0;
+  if (live) {
+    const int k1 = rowptr[r + 1];
+    for (int k = rowptr[r] + lane; k < k1; k += LPR) {
+      const int c = col[k];
+      s += val[k] * (EPI == EPI_PRE ? b[c] * dinv[c] : x[c]);
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+  if (!live || lane != 0) return;
+  if (EPI == EPI_NONE) {
+    y[r] = s;
+  } else if (EPI == EPI_RES) {
+    y[r] = b[r] - s;
+  } else if (EPI == EPI_ADD) {
+    y[r] = z[r] + s;
+  } else if (EPI == EPI_JAC) {
+    y[r] = x[r] + w * dinv[r] * (b[r] - s);
+  } else {
+    const double bb = b[r];
+    z[r] = w * dinv[r] * bb;
+    y[r] = bb - w * s;
+  }
+}
+template <int EPI>
+static void spmv_vec_launch(const Csr& a, const double* x, double* y, const double* b, double* z, const double* dinv,
+                            double w) {
+#define VEC_LAUNCH(L)                                                                                              \
+  hipLaunchKernelGGL((k_spmv_vec<L, EPI>), dim3(grid1d(a.n, 256 / L)), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, \
+                     a.val, x, y, b, z, dinv, w)
+  if (a.vec_lpr <= 16) VEC_LAUNCH(16);
+  else if (a.vec_lpr <= 32) VEC_LAUNCH(32);
+  else VEC_LAUNCH(64);
+#undef VEC_LAUNCH
+}
 // rows excluded from the slices (longer than SELL_LONG): one workgroup per row
 __global__ __launch_bounds__(256) void k_spmv_long(const int* __restrict__ rows, const int* __restrict__ rowptr,
                                                    const int* __restrict__ col, const double* __restrict__ val,
@@ -374,7 +512,7 @@ void spmv(const Csr& a, const double* x, double* y) {
   if (a.n == 0) return;
   const int per = (a.nblk + 7) / 8;
   const double abytes = (double)a.nnz * 12.0 + ((double)a.n + 1.0) * 4.0 + (double)a.n * 16.0;
-  const bool sample = g_prof.on && abytes >= g_prof.min_bytes && (g_prof.nlaunch++ % g_prof.every == 0) &&
+  const bool sample = g_prof.on && !g_capturing && abytes >= g_prof.min_bytes && (g_prof.nlaunch++ % g_prof.every == 0) &&
                       g_prof.e0.size() < 20000;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (sample) {
@@ -386,6 +524,8 @@ void spmv(const Csr& a, const double* x, double* y) {
     if (!a.rowblk) throw std::runtime_error("spmv: matrix was uploaded without LDS row blocks (GENEO_SPMV=lds at upload)");
     hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
                        a.col, a.val, x, y);
+  } else if (a.vec_lpr > 0) {
+    spmv_vec_launch<EPI_NONE>(a, x, y, nullptr, nullptr, nullptr, 0.0);
   } else {
     const int nwb = (a.nslice + 3) / 4;
     const int perw = (nwb + 7) / 8;
@@ -422,12 +562,14 @@ void spmv(const Csr& a, const double* x, double* y) {
 // LPR lanes cooperate on one row.  The row's (col,val) pairs are fetched LPR at a time with ONE
 // coalesced load per lane group and broadcast with shuffles, so the X-row loads of a chunk carry no
 // dependent global load in front of them and overlap; lane j owns output columns j, j+LPR, ...
-template <int LPR>
+template <int LPR, int EPI = 0>
 __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ rowptr,
                                               const int* __restrict__ col, const double* __restrict__ val,
                                               const double* __restrict__ X, int ldx, double* __restrict__ Y,
                                               int ldy, int m, const double* __restrict__ pre,
-                                              const double* __restrict__ post) {
+                                              const double* __restrict__ post, const double* __restrict__ B = nullptr,
+                                              int ldb = 0, double* __restrict__ Z = nullptr, int ldz = 0,
+                                              const double* __restrict__ dinv = nullptr, double w = 0.0) {
   constexpr int RPB = 256 / LPR;
   const int lane = threadIdx.x % LPR;
   const int rloc = threadIdx.x / LPR;
@@ -466,7 +608,19 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
       if (live && j < m) {
         double sacc = s0 + s1;
         if (post) sacc *= post[r];
-        Y[r * ldy + j] = sacc;
+        if (EPI == EPI_NONE) {
+          Y[r * ldy + j] = sacc;
+        } else if (EPI == EPI_RES) {
+          Y[r * ldy + j] = B[r * ldb + j] - sacc;
+        } else if (EPI == EPI_ADD) {
+          Y[r * ldy + j] = Z[r * ldz + j] + sacc;
+        } else if (EPI == EPI_JAC) {
+          Y[r * ldy + j] = X[r * ldx + j] + w * dinv[r] * (B[r * ldb + j] - sacc);
+        } else {  // EPI_PRE: X = B, pre = dinv
+          const double bb = B[r * ldb + j];
+          Z[r * ldz + j] = w * dinv[r] * bb;
+          Y[r * ldy + j] = bb - w * sacc;
+        }
       }
     }
   }
@@ -492,6 +646,55 @@ static void spmm_ld(const Csr& a, const double* X, int ldx, double* Y, int ldy, 
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post) {
   spmm_ld(a, X, ldx, Y, ldy, m, pre, post);
+}
+
+bool csr_fusable(const Csr& a) { return spmv_kind() == 1 && (a.vec_lpr > 0 || a.nlong == 0); }
+
+template <int EPI>
+static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
+                         double* Z, int ldz, const double* dinv, double w) {
+  if (m == 1 && ldx <= 1 && ldy == 1 && ldb <= 1 && ldz <= 1 && csr_fusable(a)) {  // contiguous vectors: SpMV kernels
+    if (a.vec_lpr > 0) {
+      spmv_vec_launch<EPI>(a, X, Y, B, Z, dinv, w);
+      return;
+    }
+    const int nwb = (a.nslice + 3) / 4;
+    const int perw = (nwb + 7) / 8;
+    if ((double)a.sl_nnz * 12.0 > 200e6)
+      hipLaunchKernelGGL((k_spmv_sell_epi<true, EPI>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n,
+                         a.sl_col, a.sl_val, X, Y, B, Z, dinv, w);
+    else
+      hipLaunchKernelGGL((k_spmv_sell_epi<false, EPI>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
+                         a.n, a.sl_col, a.sl_val, X, Y, B, Z, dinv, w);
+    return;
+  }
+  const double* Xin = (EPI == EPI_PRE) ? B : X;
+  const int ldin = (EPI == EPI_PRE) ? ldb : ldx;
+  const double* pre = (EPI == EPI_PRE) ? dinv : nullptr;
+  if (m <= 16) {
+    int g = std::min(grid1d(a.n, 16), 8192);
+    hipLaunchKernelGGL((k_spmm<16, EPI>), dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, Xin, ldin, Y,
+                       ldy, m, pre, nullptr, B, ldb, Z, ldz, dinv, w);
+  } else if (m <= 32) {
+    int g = std::min(grid1d(a.n, 8), 8192);
+    hipLaunchKernelGGL((k_spmm<32, EPI>), dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, Xin, ldin, Y,
+                       ldy, m, pre, nullptr, B, ldb, Z, ldz, dinv, w);
+  } else {
+    int g = std::min(grid1d(a.n, 4), 8192);
+    hipLaunchKernelGGL((k_spmm<64, EPI>), dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, Xin, ldin, Y,
+                       ldy, m, pre, nullptr, B, ldb, Z, ldz, dinv, w);
+  }
+}
+void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
+                double* Z, int ldz, const double* dinv, double w) {
+  if (a.n == 0 || m == 0) return;
+  switch (epi) {
+    case EPI_RES: spmm_fused_t<EPI_RES>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
+    case EPI_ADD: spmm_fused_t<EPI_ADD>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
+    case EPI_JAC: spmm_fused_t<EPI_JAC>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
+    case EPI_PRE: spmm_fused_t<EPI_PRE>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
+    default: throw std::runtime_error("spmm_fused: unknown epilogue");
+  }
 }
 
 __global__ void k_csr_diag(int n, const int* __restrict__ rowptr, const int* __restrict__ col,

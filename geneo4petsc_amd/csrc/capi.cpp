@@ -542,6 +542,15 @@ PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X, double* Y, int m, co
   return 0;
 }
 
+PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X, double* Y, int m, const double* B, double* Z,
+                              const double* dinv, double w) {
+  if (!h) return 1;
+  GUARD_BEGIN
+  bk::spmm_fused(h->a, epi, X, m, Y, m, m, B, m, Z, m, dinv, w);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* TC, int q,
                                 double* out, int reps, double* ms_avg) {
   GUARD_BEGIN

@@ -170,6 +170,9 @@ int PC::fail(const std::string& msg) {
 PC::~PC() { free_all(); }
 
 void PC::free_all() {
+  if (cg_graph) bk::graph_destroy(cg_graph);
+  cg_graph = nullptr;
+  cg_graph_failed = false;
   delete amg1;
   delete amgN;
   amg1 = amgN = nullptr;
@@ -687,8 +690,11 @@ void PC::local_solve(double* wL) {
   int parity = 0;
   const int check = std::max(1, use_amg ? std::min(4, opt.dls1_check) : opt.dls1_check);
   bool done = false;
-  while (!done && it < opt.dls1_max_it) {
-    for (int k = 0; k < check && it < opt.dls1_max_it; ++k, ++it) {
+  // One chunk = `check` PCG iterations with device-resident scalars (~18 small launches each with the
+  // fused V-cycle): launch-bound, so the chunk is captured once into a HIP graph and replayed.  An even
+  // chunk length brings the rz parity back to 0, which makes every chunk the same launch sequence.
+  auto chunk = [&]() {
+    for (int k = 0; k < check; ++k) {
       bk::spmv(dirL, d_cg_p, d_cg_q);
       bk::seg_pap(ch, d_cg_p, d_cg_q);
       bk::cg_update(ch, d_cg_sc, parity, x, d_cg_r, d_cg_z, d_cg_p, d_cg_q, dinv);
@@ -699,6 +705,20 @@ void PC::local_solve(double* wL) {
       bk::cg_direction(ch, d_cg_sc, parity, d_cg_p, d_cg_z, tol2);
       parity ^= 1;
     }
+  };
+  const bool graphable = (check % 2 == 0);
+  if (graphable && !cg_graph && !cg_graph_failed) {
+    if (bk::graph_capture_begin()) {
+      chunk();
+      cg_graph = bk::graph_capture_end();
+      parity = 0;
+    }
+    if (!cg_graph) cg_graph_failed = true;
+  }
+  while (!done && it < opt.dls1_max_it) {
+    if (graphable && cg_graph) bk::graph_launch(cg_graph);
+    else chunk();
+    it += check;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
     done = true;
     for (int s = 0; s < ns; ++s)
@@ -1005,12 +1025,17 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   std::vector<double> mask((size_t)ns * m, 1.0);
   double* dmask = dv((size_t)ns * m);
   owned_bufs.push_back(dmask);
+  double t_rr_host = 0.0, t_dev_wait = 0.0;
+  auto t_lob0 = clk::now();
   auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
     // Gram blocks of the leading p columns
     bk::gram(ch, S, p3, p, AS, p3, p, dGA);
     bk::gram(ch, S, p3, p, BS, p3, p, dGB);
+    auto tg0 = clk::now();
     bk::d2h(hGA.data(), dGA, sizeof(double) * (size_t)ns * p * p);
     bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p * p);
+    auto tg1 = clk::now();
+    t_dev_wait += secs(tg0, tg1);
     std::fill(hC.begin(), hC.end(), 0.0);
     auto rr_one = [&](int s) {
       std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
@@ -1053,6 +1078,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         for (auto& x : th) x.join();
       }
     }
+    t_rr_host += secs(tg1, clk::now());
     bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
     bk::block_mul(ch, S, p3, p, dC, qout, T, p3, false);
     bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
@@ -1153,6 +1179,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   info.eig_iterations += it;
   if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
   bk::sync();
+  if (getenv("GENEO_DEBUG"))
+    fprintf(stderr, "[lobpcg %s] %d iterations %.3f s: host Rayleigh-Ritz %.3f s, waiting for the Gram blocks %.3f s\n", P.label, it,
+            secs(t_lob0, clk::now()), t_rr_host, t_dev_wait);
   cleanup();
   if (!all_done) {
     // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).

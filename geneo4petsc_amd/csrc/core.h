@@ -150,6 +150,8 @@ class PC {
   bool E_chol = true;
   std::vector<double> h_yE;
   double cheb_lmax = 2.0, cheb_lmax1 = 2.0;
+  void* cg_graph = nullptr;    // HIP graph of one inner-PCG chunk (local_solve)
+  bool cg_graph_failed = false;
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 

@@ -312,6 +312,21 @@ class Spmv:
             raise GenEOError(self.lib.PCGenEOGetError(None).decode())
         return yd.to_host().reshape(self.n, m)
 
+    def fused(self, epi, X=None, B=None, Z=None, dinv=None, w=0.0):
+        """Multigrid epilogues fused into the SpMV / SpMM launch (GeneoSpmmFused); returns (Y, Z_out)."""
+        ref = X if X is not None else B
+        ref = np.asarray(ref, dtype=np.float64)
+        m = 1 if ref.ndim == 1 else ref.shape[1]
+        dev = lambda a: DeviceVector.from_host(self.lib, np.ascontiguousarray(a, dtype=np.float64).ravel()) if a is not None else None
+        xd, bd, dd = dev(X), dev(B), dev(dinv)
+        zd = dev(Z) if Z is not None else (DeviceVector(self.lib, self.n * m) if epi == 4 else None)
+        yd = DeviceVector(self.lib, self.n * m)
+        p = lambda v: v.ptr if v is not None else None
+        if self.lib.GeneoSpmmFused(self.h, int(epi), p(xd), yd.ptr, m, p(bd), p(zd), p(dd), float(w)):
+            raise GenEOError(self.lib.PCGenEOGetError(None).decode())
+        shape = (self.n,) if ref.ndim == 1 else (self.n, m)
+        return yd.to_host().reshape(shape), (zd.to_host().reshape(shape) if zd is not None else None)
+
     def algorithmic_bytes(self):
         """nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)."""
         return self.nnz * 12 + (self.n + 1) * 4 + self.n * 16

@@ -198,6 +198,10 @@ PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long
 /* Y = post.*(A (pre.*X)), row-major n x m blocks */
 PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, int m, const double* pre_dev,
                               const double* post_dev);
+/* multigrid epilogues fused into the SpMV (m = 1) / SpMM launch, row-major n x m blocks:
+ *   epi 1: Y = B - A X      2: Y = Z + A X      3: Y = X + w dinv.*(B - A X)      4: Z = w dinv.*B, Y = B - A Z */
+PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, int m, const double* B_dev,
+                              double* Z_dev, const double* dinv_dev, double w);
 /* per-subdomain tall-skinny kernels on host data (suboff: nsub+1 row offsets):
  *   kind 0: G[s] = S_s^T T_s (p x q)     kind 1: Y_s = S_s C_s (C: nsub x p x q)
  * GeneoSetMFMA(0) selects the plain-FMA twin.  reps > 0 also times it (HIP events). */

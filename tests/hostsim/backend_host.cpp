@@ -68,6 +68,31 @@ void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, in
       Y[(int64_t)i * ldy + j] = s;
     }
 }
+bool graph_capture_begin() { return false; }
+void* graph_capture_end() { return nullptr; }
+void graph_launch(void*) {}
+void graph_destroy(void*) {}
+bool csr_fusable(const Csr&) { return true; }
+void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
+                double* Z, int ldz, const double* dinv, double w) {
+  for (int i = 0; i < a.n; ++i)
+    for (int j = 0; j < m; ++j) {
+      double s = 0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int c = a.col[k];
+        s += a.val[k] * (epi == EPI_PRE ? dinv[c] * B[(int64_t)c * ldb + j] : X[(int64_t)c * ldx + j]);
+      }
+      double& y = Y[(int64_t)i * ldy + j];
+      if (epi == EPI_RES) y = B[(int64_t)i * ldb + j] - s;
+      else if (epi == EPI_ADD) y = Z[(int64_t)i * ldz + j] + s;
+      else if (epi == EPI_JAC) y = X[(int64_t)i * ldx + j] + w * dinv[i] * (B[(int64_t)i * ldb + j] - s);
+      else {
+        const double bb = B[(int64_t)i * ldb + j];
+        Z[(int64_t)i * ldz + j] = w * dinv[i] * bb;
+        y = bb - w * s;
+      }
+    }
+}
 void csr_diag(const Csr& a, double* d) {
   for (int i = 0; i < a.n; ++i) {
     double v = 0;

@@ -52,6 +52,21 @@ def test_spmv(lib, n, density, long_row, kind):
     np.testing.assert_allclose(y, a @ x, rtol=1e-13, atol=1e-13)
 
 
+def test_spmv_large_matrix_with_long_rows(lib):
+    """>= 2^18 rows: rows longer than 64 leave the sliced layout and go through the long-row kernel;
+    below that size they stay in the slices (4000-row case above, also fused epilogues)."""
+    from geneo4petsc_amd.pc import Spmv
+    n = (1 << 18) + 77
+    rng = np.random.default_rng(21)
+    rows = np.concatenate([np.repeat(np.arange(n), 3), np.full(900, 5), np.full(3000, n - 2)])
+    cols = rng.integers(0, n, size=len(rows))
+    a = sp.csr_matrix((rng.random(len(rows)) - 0.5, (rows, cols)), shape=(n, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    x = rng.random(n) - 0.5
+    np.testing.assert_allclose(Spmv(a, lib).apply(x), a @ x, rtol=1e-12, atol=1e-12)
+
+
 def test_spmv_empty_rows(lib):
     from geneo4petsc_amd.pc import Spmv
     a = sp.csr_matrix(([1.0, 2.0], ([0, 3], [1, 2])), shape=(5, 5))
@@ -79,6 +94,29 @@ def test_spmm(lib, m):
     np.testing.assert_allclose(h.spmm(X), a @ X, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(h.spmm(X, pre, post), post[:, None] * (a @ (pre[:, None] * X)), rtol=1e-12,
                                atol=1e-13)
+
+
+@pytest.mark.parametrize("density", [0.002, 0.012])
+@pytest.mark.parametrize("m", [1, 16, 32, 40])
+def test_fused_multigrid_epilogues(lib, m, density):
+    """RES / ADD / JAC / PRE epilogues on the SpMV (m = 1: sliced kernel for short rows, lanes-per-row kernel for
+    ragged ones, avg >= 20 nnz/row) and SpMM launches vs the unfused algebra."""
+    from geneo4petsc_amd.pc import Spmv
+    n = 5000
+    a = _rand_csr(n, density, 9)
+    rng = np.random.default_rng(10)
+    shape = (n,) if m == 1 else (n, m)
+    X, B, Z = rng.random(shape) - 0.5, rng.random(shape) - 0.5, rng.random(shape) - 0.5
+    dinv, w = rng.random(n) + 0.5, 0.61
+    d = dinv if m == 1 else dinv[:, None]
+    h = Spmv(a, lib)
+    tol = dict(rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(h.fused(1, X=X, B=B)[0], B - a @ X, **tol)
+    np.testing.assert_allclose(h.fused(2, X=X, Z=Z)[0], Z + a @ X, **tol)
+    np.testing.assert_allclose(h.fused(3, X=X, B=B, dinv=dinv, w=w)[0], X + w * d * (B - a @ X), **tol)
+    y, z = h.fused(4, B=B, dinv=dinv, w=w)
+    np.testing.assert_allclose(z, w * d * B, **tol)
+    np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
 
 
 @pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 48), (96, 96), (64, 32), (192, 192), (20, 12)])
