@@ -58,6 +58,7 @@ void spmv(const Csr& a, const double* x, double* y);                    // y = A
 // bracketed by two HIP events on the backend stream (no host sync until stop).
 void spmv_profile_start(int every, double min_bytes);   // only launches moving >= min_bytes algorithmic bytes
 void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
+bool spmv_profiling();   // between start and stop (callers replay one graph in eight as direct launches so that they are sampled)
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post);
@@ -132,6 +133,10 @@ void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C
 void block_residual(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
                     int m, double* R, int ldr, double* nrm);
 void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm);   // squared 2-norms
+// One pass for the LOBPCG convergence test: R = mask .* (AX - BX diag(lam)) (colmask[s*m+j], may be null) and
+// nrm3[s*3m + j] = ||AX_j - lam_j BX_j||^2 (unmasked), nrm3[s*3m + m + j] = ||AX_j||^2, nrm3[s*3m + 2m + j] = ||BX_j||^2
+void block_residual_norms(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
+                          int m, double* R, int ldr, const double* colmask, double* nrm3);
 void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m);
 // Y = a * d .* X + b * Y  (row scaling by d[i])
 void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,

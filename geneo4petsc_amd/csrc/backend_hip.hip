@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void k_spmv_long(const int* __restrict__ rows,
   if (threadIdx.x == 0) y[r] = s;
 }
 
+static inline bool sell_nt(const Csr& a) { return (double)a.sl_nnz * 12.0 > 48e6; }
 static int g_sell_variant = 0;  // tuning variants of the sliced kernel (kind = 1 + 10 * variant)
 static int g_spmv_kind = -1;  // 0 = LDS row blocks, 1 = 64-row slices
 int spmv_kind() {
@@ -489,6 +490,7 @@ void spmv_profile_start(int every, double min_bytes) {
   g_prof.nlaunch = 0;
   g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
 }
+bool spmv_profiling() { return g_prof.on; }
 void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
   g_prof.on = false;
   double ms = 0.0, by = 0.0;
@@ -532,11 +534,13 @@ void spmv(const Csr& a, const double* x, double* y) {
 #define SELL_LAUNCH(U, N)                                                                                  \
   hipLaunchKernelGGL((k_spmv_sell<U, N>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, \
                      a.sl_col, a.sl_val, x, y)
-    // default policy: 4 k-steps in flight; the (col,val) stream is marked non-temporal only when the
-    // matrix cannot stay resident in the 256 MiB Infinity Cache between launches anyway (measured:
-    // +6 % in situ at 570 MB, -20 % when a 190 MB matrix is re-read warm)
+    // default policy: 4 k-steps in flight; the once-read (col,val) stream of a large matrix is marked
+    // non-temporal so that it does not displace x and the multigrid vectors from L2 / Infinity Cache.
+    // Measured in situ (126^3 bench, 190 MB matrix, every fine-level launch sampled): 38.5 us with NT,
+    // 42.2 us without; back-to-back re-reads of the same matrix (a micro-benchmark, not the solver's
+    // access pattern) prefer the cached stream, which is why small (coarse-level) matrices keep it.
     int variant = g_sell_variant;
-    if (variant == 0) variant = ((double)a.sl_nnz * 12.0 > 200e6) ? 3 : 2;
+    if (variant == 0) variant = sell_nt(a) ? 3 : 2;
     switch (variant) {
       case 1: SELL_LAUNCH(2, true); break;
       case 2: SELL_LAUNCH(4, false); break;
@@ -660,7 +664,7 @@ static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int 
     }
     const int nwb = (a.nslice + 3) / 4;
     const int perw = (nwb + 7) / 8;
-    if ((double)a.sl_nnz * 12.0 > 200e6)
+    if (sell_nt(a))
       hipLaunchKernelGGL((k_spmv_sell_epi<true, EPI>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n,
                          a.sl_col, a.sl_val, X, Y, B, Z, dinv, w);
     else
@@ -1507,6 +1511,54 @@ void block_residual(const Chunks& c, const double* AX, int lda, const double* BX
   hipLaunchKernelGGL(k_block_residual, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, AX, lda, BX,
                      ldb, lam, m, R, ldr, part);
   hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((m + 63) / 64) * 64), 0, g_stream, c.subptr, part, m, nrm);
+}
+__global__ __launch_bounds__(256) void k_block_residual_norms(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                              const int* __restrict__ csub, const double* __restrict__ AX,
+                                                              int lda, const double* __restrict__ BX, int ldb,
+                                                              const double* __restrict__ lam, int m,
+                                                              double* __restrict__ R, int ldr,
+                                                              const double* __restrict__ mask, double* __restrict__ part) {
+  __shared__ double sm[3][256];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int tid = threadIdx.x;
+  const int rstep = 256 / m;  // m <= 85 keeps 3m <= 256 reducers
+  const int j = tid % m, rr0 = tid / m;
+  double ar = 0.0, aa = 0.0, ab = 0.0;
+  if (tid < rstep * m) {
+    const double lj = lam[(int64_t)s * m + j];
+    const double mk = mask ? mask[(int64_t)s * m + j] : 1.0;
+    for (int rr = rr0; rr < nrows; rr += rstep) {
+      const int64_t row = row0 + rr;
+      const double a = AX[row * lda + j], b = BX[row * ldb + j];
+      const double v = a - lj * b;
+      R[row * ldr + j] = mk * v;
+      ar += v * v;
+      aa += a * a;
+      ab += b * b;
+    }
+  }
+  const bool live = tid < rstep * m;
+  sm[0][tid] = live ? ar : 0.0;
+  sm[1][tid] = live ? aa : 0.0;
+  sm[2][tid] = live ? ab : 0.0;
+  __syncthreads();
+  if (tid < 3 * m) {
+    const int w = tid / m, jj = tid % m;
+    double t = 0.0;
+    for (int k = 0; k < rstep; ++k) t += sm[w][k * m + jj];
+    part[(int64_t)c * 3 * m + tid] = t;
+  }
+}
+void block_residual_norms(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
+                          int m, double* R, int ldr, const double* colmask, double* nrm3) {
+  if (c.nchunk == 0) return;
+  if (3 * m > 256) throw std::runtime_error("block_residual_norms: m > 85");
+  double* part = colpart((size_t)c.nchunk * 3 * m);
+  hipLaunchKernelGGL(k_block_residual_norms, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, AX, lda,
+                     BX, ldb, lam, m, R, ldr, colmask, part);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((3 * m + 63) / 64) * 64), 0, g_stream, c.subptr, part, 3 * m,
+                     nrm3);
 }
 __global__ __launch_bounds__(256) void k_block_colnorm(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                        const double* __restrict__ X, int ldx, int m,

@@ -100,7 +100,7 @@ PetscErrorCode PCSetFromOptions_GenEO(PC pc, int argc, const char* const* argv) 
       continue;
     }
     const bool known = k.rfind("-geneo_", 0) == 0 || k.rfind("-els2_", 0) == 0 || k.rfind("-dls1_", 0) == 0 ||
-                       k.rfind("-ksp_", 0) == 0;
+                       k.rfind("-ksp_", 0) == 0 || k.rfind("-amg_", 0) == 0;
     if (!known) continue;
     if (i + 1 >= argc) return pcfail(pc, "invalid option " + k);
     const std::string v = argv[i + 1];

@@ -162,14 +162,34 @@ std::string validate_options(const Options& o) {  // geneo.cpp:2486-2488
 }
 
 // ------------------------------------------------------------------------------------ helpers
+// AMG hierarchy of a block-diagonal matrix given by its per-subdomain blocks (host set-up)
+struct AmgHostResult {
+  std::vector<AmgLevelHost> levels;
+  std::vector<double> cinv;
+  std::vector<int64_t> cbase;
+  std::string err;
+  double secs = 0.0;
+};
+
+struct PC::Amg1Pending {
+  HostCsr mat;
+  AmgHostResult res;
+  std::thread th;
+  ~Amg1Pending() {
+    if (th.joinable()) th.join();
+  }
+};
+
 static std::string check_id(int gid, int nsub);
 int PC::fail(const std::string& msg) {
   last_error = msg;
   return 1;
 }
+PC::PC() = default;
 PC::~PC() { free_all(); }
 
 void PC::free_all() {
+  pend1.reset();
   if (cg_graph) bk::graph_destroy(cg_graph);
   cg_graph = nullptr;
   cg_graph_failed = false;
@@ -434,15 +454,6 @@ static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const s
   return upload_host(make_blockdiag(mats, suboff, colmap));
 }
 
-// AMG hierarchy of a block-diagonal matrix given by its per-subdomain blocks (host set-up)
-struct AmgHostResult {
-  std::vector<AmgLevelHost> levels;
-  std::vector<double> cinv;
-  std::vector<int64_t> cbase;
-  std::string err;
-  double secs = 0.0;
-};
-
 static AmgParams amg_params(const Options& opt) {
   AmgParams ap;
   ap.coarse_size = opt.amg_coarse_size;
@@ -450,6 +461,34 @@ static AmgParams amg_params(const Options& opt) {
   ap.smooth_ratio = opt.amg_smooth_ratio;
   ap.max_levels = opt.amg_max_levels;
   return ap;
+}
+
+// Joins the host set-up of the level-1 hierarchy (started in setup) and uploads it.
+int PC::finish_amg1() {
+  if (!pend1) return 0;
+  auto t0 = clk::now();
+  if (pend1->th.joinable()) pend1->th.join();
+  const double waited = secs(t0, clk::now());
+  std::unique_ptr<Amg1Pending> p(pend1.release());
+  if (!p->res.err.empty()) return fail(p->res.err);
+  try {
+    amg1 = new AmgDevice();
+    // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
+    amg1->upload(p->res.levels, p->res.cinv, p->res.cbase, amg_params(opt),
+                 (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
+    info.amg_levels = amg1->nlevels();
+    info.amg_operator_complexity = amg1->operator_complexity();
+  } catch (std::exception& e) {
+    return fail(e.what());
+  }
+  bk::sync();
+  const double tot = secs(t0, clk::now());
+  info.amgSetupTime += tot;
+  info.lvl1SetupMinvTimeLoc += tot;
+  if (getenv("GENEO_DEBUG"))
+    fprintf(stderr, "[amg] level-1 host set-up %.3f s on its own thread, waited %.3f s for it, upload %.3f s\n", p->res.secs, waited,
+            tot - waited);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------ setup
@@ -540,54 +579,58 @@ int PC::setup(const double* b_dev) {
     bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
   }
   {
-    // Inner AMG hierarchies: A_Dir (local solves) and A_Neu (LOBPCG).  The host set-ups are independent
-    // and device-free: they run concurrently; uploads follow on the stream.
+    // Inner AMG hierarchies: A_Neu (LOBPCG preconditioner) first -- the eigensolve is waiting for it --
+    // then A_Dir / A_Rob (local solves), whose host set-up runs on its own thread WHILE the GPU is busy
+    // with the eigensolve; it is joined and uploaded when level 2 is done (or right away without level 2).
     auto ta = clk::now();
     const bool want1 = (opt.dls1_pc == "amg");
     const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
     const AmgParams ap = amg_params(opt);
-    AmgHostResult r1, rN;
-    auto host = [&](const HostCsr* blk, AmgHostResult* r) {
+    pend1.reset(want1 ? new Amg1Pending() : nullptr);
+    if (want1) pend1->mat = std::move(h_dirL);
+    const bool overlap1 = want1 && wantN && !getenv("GENEO_AMG_NO_OVERLAP");
+    auto start1 = [this, ap]() {
+      Amg1Pending* pp = pend1.get();
+      const std::vector<int> so = suboff;
+      pp->th = std::thread([pp, so, ap]() {
+        auto t0 = clk::now();
+        try {
+          amg_setup_host(pp->mat, so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
+        } catch (std::exception& e) {
+          pp->res.err = e.what();
+        }
+        pp->res.secs = secs(t0, clk::now());
+      });
+    };
+    if (want1 && !overlap1) start1();
+    AmgHostResult rN;
+    if (wantN) {
       auto t0 = clk::now();
       try {
-        amg_setup_host(*blk, suboff, ap, r->levels, r->cinv, r->cbase);
+        amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
       } catch (std::exception& e) {
-        r->err = e.what();
+        rN.err = e.what();
       }
-      r->secs = secs(t0, clk::now());
-    };
-    std::thread th1, thN;
-    if (want1) th1 = std::thread(host, &h_dirL, &r1);
-    if (wantN) thN = std::thread(host, &h_neuL, &rN);
-    if (th1.joinable()) th1.join();
-    if (thN.joinable()) thN.join();
-    if (!r1.err.empty()) return fail(r1.err);
+      rN.secs = secs(t0, clk::now());
+    }
+    if (overlap1) start1();
     if (!rN.err.empty()) return fail(rN.err);
     try {
-      if (want1) {
-        amg1 = new AmgDevice();
-        // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
-        amg1->upload(r1.levels, r1.cinv, r1.cbase, ap, (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
-        info.amg_levels = amg1->nlevels();
-        info.amg_operator_complexity = amg1->operator_complexity();
-      }
       if (wantN) {
         const int max_m = eig_block_max();
         amgN = new AmgDevice();
         amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, max_m, &neuL);
-        if (!want1) {
-          info.amg_levels = amgN->nlevels();
-          info.amg_operator_complexity = amgN->operator_complexity();
-        }
+        info.amg_levels = amgN->nlevels();
+        info.amg_operator_complexity = amgN->operator_complexity();
       }
     } catch (std::exception& e) {
       return fail(e.what());
     }
     bk::sync();
     info.amgSetupTime = secs(ta, clk::now());
-    if (getenv("GENEO_DEBUG"))
-      fprintf(stderr, "[amg] host set-ups %.3f / %.3f s (concurrent), total with uploads %.3f s\n", r1.secs, rN.secs,
-              info.amgSetupTime);
+    if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] A_Neu host set-up %.3f s, with upload %.3f s\n", rN.secs, info.amgSetupTime);
+    if (want1 && !opt.lvl2)
+      if (int rc = finish_amg1()) return rc;
   }
   bk::sync();
   info.lvl1SetupMinvTimeLoc = secs(t1, clk::now());
@@ -716,7 +759,10 @@ void PC::local_solve(double* wL) {
     if (!cg_graph) cg_graph_failed = true;
   }
   while (!done && it < opt.dls1_max_it) {
-    if (graphable && cg_graph) bk::graph_launch(cg_graph);
+    // while the in-situ SpMV timer runs, one chunk in eight goes out as direct launches: HIP events cannot
+    // bracket kernels inside a replayed graph, and the sampled launches are the very same kernels
+    const bool direct = bk::spmv_profiling() && (cg_chunks++ % 8 == 0);
+    if (graphable && cg_graph && !direct) bk::graph_launch(cg_graph);
     else chunk();
     it += check;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
@@ -832,6 +878,8 @@ int PC::setup_level2(const double* b_dev) {
   bk::sync();
   auto t1 = clk::now();
   info.lvl2SetupEigTimeLoc = secs(t0, t1);
+  if (int r1 = finish_amg1()) return r1;
+  t1 = clk::now();
   try {
     if (opt.check)
       if (int rc = check_local_rank()) return rc;
@@ -1025,6 +1073,10 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   std::vector<double> mask((size_t)ns * m, 1.0);
   double* dmask = dv((size_t)ns * m);
   owned_bufs.push_back(dmask);
+  double* dn3 = dv((size_t)ns * 3 * m);
+  owned_bufs.push_back(dn3);
+  std::vector<double> n3((size_t)ns * 3 * m);
+  bool have_mask = false;
   double t_rr_host = 0.0, t_dev_wait = 0.0;
   auto t_lob0 = clk::now();
   auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
@@ -1058,7 +1110,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
           for (int i = 0; i < p; ++i) {
             const double v = C[(size_t)i * r + j];
             cs[(size_t)i * qout + j] = v;
-            if (with_p && i >= m) cs[(size_t)i * qout + m + j] = v;  // P = S C with the X rows zeroed
+            if (with_p && i >= m && !locked[(size_t)s * m + j]) cs[(size_t)i * qout + m + j] = v;  // P = S C, X rows zeroed
           }
         } else {
           lam[(size_t)s * m + j] = 1e300;  // fewer independent directions than m
@@ -1103,19 +1155,23 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     // the A X / B X blocks are carried by recurrence (A S C); refresh them explicitly every few
     // iterations so that rounding drift (eps * ||A|| ||x|| per update, large for high-contrast
     // operators) cannot accumulate into the residual
-    if (it > 0 && it % 8 == 0) {
+    static const int refresh = getenv("GENEO_LOBPCG_REFRESH") ? atoi(getenv("GENEO_LOBPCG_REFRESH")) : 8;
+    if (it > 0 && refresh > 0 && it % refresh == 0) {
       applyA(S, AS);
       applyB(S, BS);
     }
     // residual into the W slot, convergence test
     bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
     double* W = S + 2 * m;
-    bk::block_residual(ch, AS, p3, BS, p3, dlam, m, cr, m, dnr);
-    bk::block_colnorm(ch, AS, p3, m, dna);
-    bk::block_colnorm(ch, BS, p3, m, dnb);
-    bk::d2h(nr.data(), dnr, sizeof(double) * (size_t)ns * m);
-    bk::d2h(na.data(), dna, sizeof(double) * (size_t)ns * m);
-    bk::d2h(nb.data(), dnb, sizeof(double) * (size_t)ns * m);
+    // one pass: residual block (columns locked in EARLIER iterations come out zero) + the three norms
+    bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, have_mask ? dmask : nullptr, dn3);
+    bk::d2h(n3.data(), dn3, sizeof(double) * (size_t)ns * 3 * m);
+    for (int s = 0; s < ns; ++s)
+      for (int j = 0; j < m; ++j) {
+        nr[(size_t)s * m + j] = n3[(size_t)s * 3 * m + j];
+        na[(size_t)s * m + j] = n3[(size_t)s * 3 * m + m + j];
+        nb[(size_t)s * m + j] = n3[(size_t)s * 3 * m + 2 * m + j];
+      }
     all_done = true;
     for (int s = 0; s < ns; ++s) {
       if (frozen[s]) continue;
@@ -1126,7 +1182,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         res[s][j] = den > 0 ? std::sqrt(nr[e]) / den : 0.0;
         // soft locking: a converged pair stays in X (and in the Rayleigh-Ritz) but no longer
         // contributes search directions -- its W / P columns would only inject rounding noise
-        if (lam[e] >= 1e299 || res[s][j] <= tol) locked[e] = 1;
+        static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
+        if (lam[e] >= 1e299 || (res[s][j] <= tol && !nolock)) locked[e] = 1;
+        if (nolock && j < nev_s[s] && res[s][j] > tol) sub_done = false;
         if (j < nev_s[s] && !locked[e]) sub_done = false;
       }
       if (sub_done) frozen[s] = 1;
@@ -1142,17 +1200,17 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
     }
     if (all_done || it == opt.eps_max_it) break;
-    bool any_locked = false;
+    // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
+    // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
+    bool changed = false;
     for (size_t e = 0; e < locked.size(); ++e) {
-      mask[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-      if (mask[e] == 0.0) any_locked = true;
+      const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+      if (mk != mask[e]) changed = true;
+      mask[e] = mk;
     }
-    if (any_locked) {
+    if (changed) {
       bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
-      bk::block_colscale(ch, cr, m, m, dmask);
-      bk::block_colscale(ch, S + m, p3, m, dmask);
-      bk::block_colscale(ch, AS + m, p3, m, dmask);
-      bk::block_colscale(ch, BS + m, p3, m, dmask);
+      have_mask = true;
     }
     if (P.amg) {
       // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
@@ -1360,6 +1418,7 @@ int PC::eigen_lobpcg() {
   }
   if (g2) {
     if (int rc = local_gamma()) { release(); return rc; }
+    if (int rc = finish_amg1()) { release(); return rc; }   // the gamma problem runs through the level-1 hierarchy
     EigProblem pg{&dirL, nullptr, &dirB, d_D, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
                   d_dinv1, cheb_lmax1, nev_try, "gamma"};
     if (opt.check) {  // the reference checks the B of the gamma pencil as given to SLEPc: A_Rob (geneo.cpp:1299,:884)

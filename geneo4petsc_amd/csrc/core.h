@@ -2,6 +2,7 @@
 // MI355X-native counterpart of /root/reference/src/geneo.cpp; see DESIGN.md for the map.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,7 @@ class PC {
   double *comm_send = nullptr, *comm_recv = nullptr, *comm_red = nullptr;  // device buffers owned by the caller
   int comm_red_cap = 0;
 
+  PC();
   ~PC();
   int add_subdomain(int gid, int n, const int* l2g, const int* mult, const int* neu_rowptr, const int* neu_col,
                     const double* neu_val, const int* dir_rowptr, const int* dir_col, const double* dir_val);
@@ -150,8 +152,12 @@ class PC {
   bool E_chol = true;
   std::vector<double> h_yE;
   double cheb_lmax = 2.0, cheb_lmax1 = 2.0;
+  struct Amg1Pending;
+  std::unique_ptr<Amg1Pending> pend1;   // level-1 hierarchy whose host set-up is still running
+  int finish_amg1();
   void* cg_graph = nullptr;    // HIP graph of one inner-PCG chunk (local_solve)
   bool cg_graph_failed = false;
+  long long cg_chunks = 0;
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 

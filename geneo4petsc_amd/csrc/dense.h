@@ -79,10 +79,13 @@ inline void lu_solve(const std::vector<double>& a, int n, const std::vector<int>
 // implicit QL iteration (the classical tred2 / tql2 pair).  A is n x n row-major and is destroyed.
 // Eigenvalues ascending in w, eigenvectors in the COLUMNS of v (row-major n x n).
 inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::vector<double>& v) {
-  v = a;  // work in v: v[i*n+j]
+  // The algorithm walks down columns (first index) in its inner loops: the working copy is held
+  // transposed (A is symmetric, so the input needs no transposition) to make those walks contiguous
+  // and vectorisable; the eigenvectors are transposed back while sorting.
+  v = a;
   w.assign(n, 0.0);
   std::vector<double> e(n, 0.0);
-  auto V = [&](int i, int j) -> double& { return v[(size_t)i * n + j]; };
+  auto V = [&](int i, int j) -> double& { return v[(size_t)j * n + i]; };
   if (n == 0) return;
   // ---- tred2
   for (int j = 0; j < n; ++j) w[j] = V(n - 1, j);
@@ -219,7 +222,8 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
   std::vector<double> ws(n), vs((size_t)n * n);
   for (int j = 0; j < n; ++j) {
     ws[j] = w[ord[j]];
-    for (int k = 0; k < n; ++k) vs[(size_t)k * n + j] = v[(size_t)k * n + ord[j]];
+    const double* src = v.data() + (size_t)ord[j] * n;   // eigenvector ord[j], contiguous in the working copy
+    for (int k = 0; k < n; ++k) vs[(size_t)k * n + j] = src[k];
   }
   w.swap(ws);
   v.swap(vs);
@@ -270,12 +274,15 @@ inline int gen_eig_rr(const std::vector<double>& GA, const std::vector<double>& 
     }
     const double piv = std::sqrt(dg[pick]);
     std::vector<double> col(p, 0.0);
-    for (int i : cand) {
-      if (used[i] && i != pick) continue;
-      double s = GB[i * p + pick] * sc[i] * sc[pick];
-      for (size_t k = 0; k < lrow.size(); ++k) s -= lrow[k][i] * lrow[k][pick];
-      col[i] = s / piv;
+    for (int i : cand) col[i] = GB[i * p + pick] * sc[i] * sc[pick];
+    for (size_t k = 0; k < lrow.size(); ++k) {       // col -= L(:, k) L(pick, k), contiguous in i
+      const double f = lrow[k][pick];
+      const double* lk = lrow[k].data();
+      for (int i = 0; i < p; ++i) col[i] -= lk[i] * f;
     }
+    for (int i : cand) col[i] = (used[i] && i != pick) ? 0.0 : col[i] / piv;
+    for (int i = 0; i < p; ++i)
+      if (sc[i] == 0.0) col[i] = 0.0;
     col[pick] = piv;
     for (int i : cand)
       if (!used[i]) dg[i] -= col[i] * col[i];
@@ -294,33 +301,45 @@ inline int gen_eig_rr(const std::vector<double>& GA, const std::vector<double>& 
   std::vector<double> M((size_t)r * r);
   for (int a = 0; a < r; ++a)
     for (int b = 0; b < r; ++b) M[a * r + b] = GA[kept[a] * p + kept[b]] * sc[kept[a]] * sc[kept[b]];
-  for (int col = 0; col < r; ++col)  // M <- Lk^-1 M (forward substitution per column)
+  auto lower_solve_rows = [&](std::vector<double>& X) {  // X <- Lk^-1 X, whole rows at a time (contiguous)
     for (int i = 0; i < r; ++i) {
-      double s = M[i * r + col];
-      for (int k = 0; k < i; ++k) s -= Lk[i * r + k] * M[k * r + col];
-      M[i * r + col] = s / Lk[i * r + i];
+      double* xi = X.data() + (size_t)i * r;
+      for (int k = 0; k < i; ++k) {
+        const double f = Lk[i * r + k];
+        const double* xk = X.data() + (size_t)k * r;
+        for (int c = 0; c < r; ++c) xi[c] -= f * xk[c];
+      }
+      const double inv = 1.0 / Lk[i * r + i];
+      for (int c = 0; c < r; ++c) xi[c] *= inv;
     }
-  for (int row = 0; row < r; ++row)  // M <- M Lk^-T
-    for (int j = 0; j < r; ++j) {
-      double s = M[row * r + j];
-      for (int k = 0; k < j; ++k) s -= M[row * r + k] * Lk[j * r + k];
-      M[row * r + j] = s / Lk[j * r + j];
-    }
+  };
+  lower_solve_rows(M);                                   // T = Lk^-1 M
+  {                                                      // Lk^-1 M Lk^-T = Lk^-1 T^T (the result is symmetric)
+    std::vector<double> Tt((size_t)r * r);
+    for (int a = 0; a < r; ++a)
+      for (int b = 0; b < r; ++b) Tt[(size_t)b * r + a] = M[(size_t)a * r + b];
+    M.swap(Tt);
+  }
+  lower_solve_rows(M);
   for (int a = 0; a < r; ++a)  // symmetrise
     for (int b = a + 1; b < r; ++b) M[a * r + b] = M[b * r + a] = 0.5 * (M[a * r + b] + M[b * r + a]);
   std::vector<double> w, V;
   sym_eig(M, r, w, V);
   theta = w;
-  // C[kept, :] = D Lk^-T V
-  for (int j = 0; j < r; ++j) {
-    std::vector<double> y(r);
-    for (int i = 0; i < r; ++i) y[i] = V[i * r + j];
-    for (int i = r - 1; i >= 0; --i) {  // solve Lk^T z = y
-      double s = y[i];
-      for (int k = i + 1; k < r; ++k) s -= Lk[k * r + i] * y[k];
-      y[i] = s / Lk[i * r + i];
+  // C[kept, :] = D Lk^-T V : back substitution on all eigenvectors at once, row by row
+  for (int i = r - 1; i >= 0; --i) {
+    double* zi = V.data() + (size_t)i * r;
+    for (int k = i + 1; k < r; ++k) {
+      const double f = Lk[k * r + i];
+      const double* zk = V.data() + (size_t)k * r;
+      for (int c = 0; c < r; ++c) zi[c] -= f * zk[c];
     }
-    for (int i = 0; i < r; ++i) C[(size_t)kept[i] * r + j] = y[i] * sc[kept[i]];
+    const double inv = 1.0 / Lk[i * r + i];
+    for (int c = 0; c < r; ++c) zi[c] *= inv;
+  }
+  for (int i = 0; i < r; ++i) {
+    const double f = sc[kept[i]];
+    for (int j = 0; j < r; ++j) C[(size_t)kept[i] * r + j] = V[(size_t)i * r + j] * f;
   }
   return r;
 }

@@ -102,6 +102,8 @@ def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, x
     assert np.linalg.norm(y1 - y2) <= aptol * np.linalg.norm(y2)
     m1, m2 = pc.matmult(b), orc.matmult(b)
     assert np.linalg.norm(m1 - m2) <= 1e-13 * np.linalg.norm(m2)
-    assert np.linalg.norm(x - res.x) <= xtol * np.linalg.norm(res.x)
+    # same iterate when the counts agree; otherwise two different iterates of the same convergent sequence,
+    # each within the Krylov tolerance of the solution
+    assert np.linalg.norm(x - res.x) <= (xtol if its == res.its else 5 * xtol) * np.linalg.norm(res.x)
     pc.destroy()
     return its, info

@@ -51,6 +51,7 @@ void spmv(const Csr& a, const double* x, double* y) {
   }
 }
 void spmv_profile_start(int, double) {}
+bool spmv_profiling() { return false; }
 void spmv_profile_stop(double* a, double* b, long long* c, long long* d) {
   if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; if (d) *d = 0;
 }
@@ -281,6 +282,24 @@ void block_residual(const Chunks& c, const double* AX, int lda, const double* BX
         t += v * v;
       }
       nrm[(int64_t)s * m + j] = t;
+    }
+}
+void block_residual_norms(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
+                          int m, double* R, int ldr, const double* colmask, double* nrm3) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int j = 0; j < m; ++j) {
+      double tr = 0, ta = 0, tb = 0;
+      const double lj = lam[(int64_t)s * m + j];
+      const double mk = colmask ? colmask[(int64_t)s * m + j] : 1.0;
+      for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+        const double a = AX[(int64_t)i * lda + j], b = BX[(int64_t)i * ldb + j];
+        const double v = a - lj * b;
+        R[(int64_t)i * ldr + j] = mk * v;
+        tr += v * v; ta += a * a; tb += b * b;
+      }
+      nrm3[(int64_t)s * 3 * m + j] = tr;
+      nrm3[(int64_t)s * 3 * m + m + j] = ta;
+      nrm3[(int64_t)s * 3 * m + 2 * m + j] = tb;
     }
 }
 void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm) {

@@ -37,7 +37,7 @@ def test_mfma_lane_map(lib):
     assert lib.GeneoSelfTestMFMA() == 0
 
 
-@pytest.mark.parametrize("kind", [1, 0])
+@pytest.mark.parametrize("kind", [1, 0, 21, 31])     # sliced (default policy), LDS row blocks, cached / non-temporal stream
 @pytest.mark.parametrize("n,density,long_row", [(1, 1.0, None), (257, 0.02, None), (5000, 0.002, None),
                                                 (4000, 0.001, 17), (70000, 0.0001, None), (130, 0.6, None)])
 def test_spmv(lib, n, density, long_row, kind):
