@@ -149,11 +149,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, size))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: the GenEO hot path has no CPU fallback")
+    # GENEO_BENCH_COMM=staged: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, gloo + host-staged halo exchange); the driver's multi-GPU runs use RCCL (backend "nccl").
+    staged = os.environ.get("GENEO_BENCH_COMM") == "staged"
+    if staged:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cpu" if staged else "cuda"
     if size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from geneo4petsc_amd import _lib
     from geneo4petsc_amd.pc import GenEOPC, DeviceVector
@@ -164,8 +173,8 @@ def main():
     n, nb, doms, plan, b = build_problem(args, rank, size)
     comm = None
     if size > 1:
-        from geneo4petsc_amd.comm import TorchComm
-        comm = TorchComm(plan, torch.device("cuda", local_rank))
+        from geneo4petsc_amd.comm import TorchComm, StagedComm
+        comm = StagedComm(plan, lib) if staged else TorchComm(plan, torch.device("cuda", local_rank))
     prep_s = time.perf_counter() - t_prep
     argv = geneo_argv(args)
     bd = DeviceVector.from_host(lib, b)
@@ -218,10 +227,10 @@ def main():
     local = {"elapsed": elapsed, "spmv_ms": ms_sum.value, "spmv_bytes": by_sum.value, "setup": info["setupTime"],
              "solve": info["solveTime"]}
     if dist is not None:
-        t = torch.tensor([elapsed, info["setupTime"], info["solveTime"]], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, info["setupTime"], info["solveTime"]], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, setup_s, solve_s = [float(v) for v in t.tolist()]
-        g = torch.tensor([by_sum.value / max(ms_sum.value, 1e-9) * 1e-6], device="cuda", dtype=torch.float64)
+        g = torch.tensor([by_sum.value / max(ms_sum.value, 1e-9) * 1e-6], device=red_dev, dtype=torch.float64)
         dist.all_reduce(g)                      # aggregate GB/s over ranks
         agg_gbs = float(g.item())
     else:

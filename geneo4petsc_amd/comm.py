@@ -57,6 +57,54 @@ class TorchComm:
                     self.red.data_ptr(), self.red_capacity)
 
 
+class StagedComm(TorchComm):
+    """Same two exchange steps through host staging: the library's device buffers are copied to CPU tensors,
+    moved with a CPU backend (gloo) and copied back.  For clusters whose transport cannot take device pointers,
+    and for rehearsing the N > 1 path of the HIP library with several ranks on ONE GPU (tests/test_gpu_multirank.py)."""
+
+    def __init__(self, plan, lib, red_capacity=8192):
+        super().__init__(plan, "cpu", red_capacity)
+        from .pc import DeviceVector
+        self.lib = lib
+        cap = max(1, self.nsend, self.nrecv)
+        self.d_send, self.d_recv = DeviceVector(lib, cap), DeviceVector(lib, cap)
+        self.d_red = DeviceVector(lib, red_capacity)
+
+    def _down(self, dev, host, n):
+        if n and self.lib.GeneoD2H(host.data_ptr(), dev.ptr, n * 8):
+            raise RuntimeError("D2H failed")
+
+    def _up(self, dev, host, n):
+        if n and self.lib.GeneoH2D(dev.ptr, host.data_ptr(), n * 8):
+            raise RuntimeError("H2D failed")
+
+    def exchange(self, user, reverse):
+        try:
+            nout, nin = (self.nrecv, self.nsend) if reverse else (self.nsend, self.nrecv)
+            self._down(self.d_send, self.send, nout)
+            rc = super().exchange(user, reverse)
+            self._up(self.d_recv, self.recv, nin)
+            return rc
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def allreduce(self, user, n):
+        try:
+            self._down(self.d_red, self.red, n)
+            rc = super().allreduce(user, n)
+            self._up(self.d_red, self.red, n)
+            return rc
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def attach(self, pc):
+        p = self.plan
+        pc.set_comm(p.rank, p.size, p.owned, p.halo_gid, p.recv_counts, p.send_counts, p.send_idx,
+                    self.exchange, self.allreduce, self.d_send.ptr, self.d_recv.ptr, self.d_red.ptr, self.red_capacity)
+
+
 def gather_owned(x_owned, plan, n_global):
     """Test helper: assemble a global numpy vector from every rank's owned part."""
     import torch

@@ -1,0 +1,14 @@
+#!/bin/bash
+# rehearsal of bench.py's N > 1 path on the one-GPU box: ranks share cuda:0, gloo + host-staged exchange
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0 GENEO_BENCH_COMM=staged MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=2
+for N in 2 4; do
+  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2955$N \
+     bench.py --gpus $N --steps 1 --warmup 1 --n-per-gpu 64 --no-cpu-baseline > $O/bench_staged_n$N.log 2>&1
+  rc=$?; echo "bench staged N=$N exit $rc"; tail -2 $O/bench_staged_n$N.log | cut -c1-1500
+  [ $rc -eq 0 ] || exit $rc
+done

@@ -18,6 +18,7 @@ def main():
     out_path, lvl, ksp = sys.argv[1], sys.argv[2], sys.argv[3]
     parts = tuple(int(t) for t in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 2, 2)
     extra = sys.argv[5:]
+    use_hip = os.environ.get("GENEO_WORKER_LIB") == "hip"     # tests/test_gpu_multirank.py: both ranks on cuda:0
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     import hostsim_util as hu
@@ -29,8 +30,18 @@ def main():
     sub_rank = np.arange(nb) * size // nb
     doms = [decomp.decompose_grid_domain(n, 3, parts, ov, s) for s in range(nb) if sub_rank[s] == rank]
     plan = decomp.grid_rank_plan(n, 3, parts, ov, sub_rank, rank, size, doms)
-    lib = hu.hostsim_lib()
-    comm = TorchComm(plan, "cpu")
+    if use_hip:
+        from geneo4petsc_amd import _lib
+        from geneo4petsc_amd.comm import StagedComm
+        lib = _lib.load()
+        comm = StagedComm(plan, lib)
+    elif os.environ.get("GENEO_WORKER_LIB") == "staged":      # StagedComm logic itself, on the CPU backend
+        from geneo4petsc_amd.comm import StagedComm
+        lib = hu.hostsim_lib()
+        comm = StagedComm(plan, lib)
+    else:
+        lib = hu.hostsim_lib()
+        comm = TorchComm(plan, "cpu")
     pc = GenEOPC(lib)
     pc.set_from_options(["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp,
                          "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"] + extra)
