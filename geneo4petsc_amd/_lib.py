@@ -80,6 +80,7 @@ SYMBOLS = {
     "PCGenEOGetE": (C.c_int, [C.c_void_p, c_dbl_p, C.c_int]),
     "PCGenEOGetLocalDims": (C.c_int, [C.c_void_p, c_int_p, C.c_int]),
     "PCGenEOGetLocalParams": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p, C.c_int]),
+    "PCGenEOSetCommWidth": (C.c_int, [C.c_void_p, C.c_int]),
     "PCGenEOSetIntersect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p]),
     "GeneoGetLibInput": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GeneoInput)]),
     "GeneoFreeInput": (None, [C.POINTER(GeneoInput)]),

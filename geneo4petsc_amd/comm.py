@@ -12,7 +12,9 @@ import numpy as np
 
 
 class TorchComm:
-    def __init__(self, plan, device, red_capacity=8192):
+    WIDTH = 32     # vectors per halo exchange the buffers are sized for (blocked assembly of E)
+
+    def __init__(self, plan, device, red_capacity=1 << 16):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -20,23 +22,24 @@ class TorchComm:
         self.send_counts = [int(c) for c in plan.send_counts]
         self.recv_counts = [int(c) for c in plan.recv_counts]
         self.nsend, self.nrecv = sum(self.send_counts), sum(self.recv_counts)
-        cap = max(1, self.nsend, self.nrecv)
+        cap = max(1, self.nsend, self.nrecv) * self.WIDTH
         self.send = torch.zeros(cap, dtype=torch.float64, device=device)
         self.recv = torch.zeros(cap, dtype=torch.float64, device=device)
         self.red = torch.zeros(red_capacity, dtype=torch.float64, device=device)
         self.red_capacity = red_capacity
         self.error = None
 
-    def exchange(self, user, reverse):
+    def exchange(self, user, flag):
         try:
+            reverse, w = flag & 1, max(1, flag >> 1)      # w vectors per entry, entry-major
+            sc = self.send_counts if w == 1 else [c * w for c in self.send_counts]
+            rc = self.recv_counts if w == 1 else [c * w for c in self.recv_counts]
             if reverse:   # halo contributions travel back to their owners
-                self.dist.all_to_all_single(self.recv[:self.nsend], self.send[:self.nrecv],
-                                            output_split_sizes=self.send_counts,
-                                            input_split_sizes=self.recv_counts)
+                self.dist.all_to_all_single(self.recv[:self.nsend * w], self.send[:self.nrecv * w],
+                                            output_split_sizes=sc, input_split_sizes=rc)
             else:         # owners send the values of their DOFs to every rank that overlaps them
-                self.dist.all_to_all_single(self.recv[:self.nrecv], self.send[:self.nsend],
-                                            output_split_sizes=self.recv_counts,
-                                            input_split_sizes=self.send_counts)
+                self.dist.all_to_all_single(self.recv[:self.nrecv * w], self.send[:self.nsend * w],
+                                            output_split_sizes=rc, input_split_sizes=sc)
             return 0
         except Exception as e:   # never let an exception cross the C boundary
             self.error = e
@@ -55,6 +58,7 @@ class TorchComm:
         pc.set_comm(p.rank, p.size, p.owned, p.halo_gid, p.recv_counts, p.send_counts, p.send_idx,
                     self.exchange, self.allreduce, self.send.data_ptr(), self.recv.data_ptr(),
                     self.red.data_ptr(), self.red_capacity)
+        pc.set_comm_width(self.WIDTH)
 
 
 class StagedComm(TorchComm):
@@ -62,11 +66,11 @@ class StagedComm(TorchComm):
     moved with a CPU backend (gloo) and copied back.  For clusters whose transport cannot take device pointers,
     and for rehearsing the N > 1 path of the HIP library with several ranks on ONE GPU (tests/test_gpu_multirank.py)."""
 
-    def __init__(self, plan, lib, red_capacity=8192):
+    def __init__(self, plan, lib, red_capacity=1 << 16):
         super().__init__(plan, "cpu", red_capacity)
         from .pc import DeviceVector
         self.lib = lib
-        cap = max(1, self.nsend, self.nrecv)
+        cap = max(1, self.nsend, self.nrecv) * self.WIDTH
         self.d_send, self.d_recv = DeviceVector(lib, cap), DeviceVector(lib, cap)
         self.d_red = DeviceVector(lib, red_capacity)
 
@@ -78,12 +82,13 @@ class StagedComm(TorchComm):
         if n and self.lib.GeneoH2D(dev.ptr, host.data_ptr(), n * 8):
             raise RuntimeError("H2D failed")
 
-    def exchange(self, user, reverse):
+    def exchange(self, user, flag):
         try:
+            reverse, w = flag & 1, max(1, flag >> 1)
             nout, nin = (self.nrecv, self.nsend) if reverse else (self.nsend, self.nrecv)
-            self._down(self.d_send, self.send, nout)
-            rc = super().exchange(user, reverse)
-            self._up(self.d_recv, self.recv, nin)
+            self._down(self.d_send, self.send, nout * w)
+            rc = super().exchange(user, flag)
+            self._up(self.d_recv, self.recv, nin * w)
             return rc
         except Exception as e:
             self.error = e
@@ -103,6 +108,7 @@ class StagedComm(TorchComm):
         p = self.plan
         pc.set_comm(p.rank, p.size, p.owned, p.halo_gid, p.recv_counts, p.send_counts, p.send_idx,
                     self.exchange, self.allreduce, self.d_send.ptr, self.d_recv.ptr, self.d_red.ptr, self.red_capacity)
+        pc.set_comm_width(self.WIDTH)
 
 
 def gather_owned(x_owned, plan, n_global):

@@ -80,6 +80,10 @@ void gather_mul(double* out, const double* in, const int* idx, const double* d, 
 // out[e] (+)= sum_{k in [ptr[e],ptr[e+1])} in[idx[k]]   (fixed order)
 void segsum(double* out, const double* in, const int* ptr, const int* idx, int nseg, bool accumulate);
 
+// row-major blocks of w columns (ld = w): out[i][:] = in[idx[i]][:] ; out[e][:] (+)= sum_k in[idx[k]][:]
+void gather_rows(double* out, const double* in, const int* idx, int n, int w);
+void segsum_rows(double* out, const double* in, const int* ptr, const int* idx, int nseg, int w, bool accumulate);
+
 // ---- BLAS-1 --------------------------------------------------------------------------------
 void set(double* x, double v, int n);
 void copy(double* y, const double* x, int n);
@@ -171,6 +175,9 @@ bool  graph_capture_begin();          // false: capture unavailable (the caller 
 void* graph_capture_end();            // executable graph (nullptr on failure)
 void  graph_launch(void* exec);
 void  graph_destroy(void* exec);
+
+// ZR (n_L x kp row-major, zero padded) from the per-subdomain column-major Z (blocked assembly of E)
+void z_rowmajor(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, double* ZR, int kp);
 
 // ---- misc -------------------------------------------------------------------------------------
 void  set_spmv_kind(int kind);  // 0: LDS row-block kernel, 1: 64-row sliced kernel (default)

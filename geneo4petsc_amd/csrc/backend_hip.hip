@@ -118,6 +118,8 @@ static inline int grid1d(int64_t n, int per_block) {
   return g < 1 ? 1 : g;
 }
 
+static inline int gridv(int64_t n) { return std::min(grid1d(n, 1024), 2048); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -742,6 +744,35 @@ __global__ void k_segsum(double* __restrict__ out, const double* __restrict__ in
     out[e] = acc ? out[e] + s : s;
   }
 }
+__global__ void k_gather_rows(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ idx,
+                              int64_t n, int w) {
+  const int64_t tot = n * w;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / w;
+    const int j = (int)(e - i * w);
+    out[e] = in[(int64_t)idx[i] * w + j];
+  }
+}
+void gather_rows(double* out, const double* in, const int* idx, int n, int w) {
+  if (n <= 0 || w <= 0) return;
+  hipLaunchKernelGGL(k_gather_rows, dim3(gridv((int64_t)n * w)), dim3(256), 0, g_stream, out, in, idx, (int64_t)n, w);
+}
+__global__ void k_segsum_rows(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ ptr,
+                              const int* __restrict__ idx, int64_t nseg, int w, int acc) {
+  const int64_t tot = nseg * w;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / w;
+    const int j = (int)(e - r * w);
+    double s = 0.0;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) s += in[(int64_t)idx[k] * w + j];   // fixed order
+    out[e] = acc ? out[e] + s : s;
+  }
+}
+void segsum_rows(double* out, const double* in, const int* ptr, const int* idx, int nseg, int w, bool accumulate) {
+  if (nseg <= 0 || w <= 0) return;
+  hipLaunchKernelGGL(k_segsum_rows, dim3(gridv((int64_t)nseg * w)), dim3(256), 0, g_stream, out, in, ptr, idx,
+                     (int64_t)nseg, w, accumulate ? 1 : 0);
+}
 void segsum(double* out, const double* in, const int* ptr, const int* idx, int nseg, bool accumulate) {
   if (nseg <= 0) return;
   hipLaunchKernelGGL(k_segsum, dim3(std::min(grid1d(nseg, 256), 4096)), dim3(256), 0, g_stream, out, in, ptr,
@@ -766,7 +797,6 @@ __global__ void k_axpy_dev(double* __restrict__ y, const double* __restrict__ a,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] += s * x[i];
 }
-static inline int gridv(int64_t n) { return std::min(grid1d(n, 1024), 2048); }
 void set(double* x, double v, int n) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_set, dim3(gridv(n)), dim3(256), 0, g_stream, x, v, (int64_t)n);
@@ -1736,6 +1766,28 @@ void block_extract(const Chunks& c, const double* X, int ldx, int m, const doubl
   if (c.nchunk == 0) return;
   hipLaunchKernelGGL(k_block_extract, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, X,
                      ldx, m, d, sel, ksub, zbase, Z);
+}
+
+__global__ __launch_bounds__(256) void k_z_rowmajor(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                    const int* __restrict__ csub, const int* __restrict__ suboff,
+                                                    const double* __restrict__ Z, const int64_t* __restrict__ zbase,
+                                                    const int* __restrict__ ksub, double* __restrict__ ZR, int kp) {
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], s = csub[c];
+  const int k = ksub[s];
+  const int srow0 = suboff[s];
+  const int ns = suboff[s + 1] - srow0;
+  const double* Zs = Z + zbase[s];
+  for (int j = 0; j < kp; ++j)
+    for (int rr = threadIdx.x; rr < nrows; rr += 256) {
+      const int64_t row = row0 + rr;
+      ZR[row * kp + j] = (j < k) ? Zs[(int64_t)j * ns + (row - srow0)] : 0.0;
+    }
+}
+void z_rowmajor(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, double* ZR, int kp) {
+  if (c.nchunk == 0) return;
+  hipLaunchKernelGGL(k_z_rowmajor, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, Z, zbase,
+                     ksub, ZR, kp);
 }
 
 // =============================================================================== coarse space

@@ -259,6 +259,13 @@ PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int*
   return 0;
 }
 
+PetscErrorCode PCGenEOSetCommWidth(PC pc, int max_width) {
+  if (!pc || !pc->ctx) return 1;
+  if (max_width < 1) return pcfail(pc, "GenEO: bad halo buffer width");
+  pc->ctx->comm_width = max_width;
+  return 0;
+}
+
 PetscErrorCode PCGenEOSetRHS(PC pc, const double* b_dev) {
   if (!pc) return 1;
   pc->b_dev = b_dev;

@@ -712,6 +712,50 @@ int PC::matmult(const double* x, double* y) {
   return 0;
 }
 
+// ---- the same three operators on row-major blocks of w vectors (blocked assembly of E) ----------------
+// The halo buffers hold comm_width x the single-vector counts; the exchange callback gets the width in
+// the upper bits of its flag (flag = reverse | width << 1).
+void PC::restrict_block(const double* X, double* XL, int w, double* xe) {
+  if (size == 1) {
+    bk::gather_rows(XL, X, d_l2e, nL, w);
+    return;
+  }
+  const int nown = n_owned();
+  bk::gather_rows(comm_send, X, d_send_idx, (int)send_idx.size(), w);
+  if (cb_exchange(cb_user, 0 | (w << 1))) throw std::runtime_error("GenEO: halo exchange callback failed");
+  bk::copy(xe, X, (int)((int64_t)nown * w));
+  bk::copy(xe + (int64_t)nown * w, comm_recv, (int)((int64_t)nH * w));
+  bk::gather_rows(XL, xe, d_l2e, nL, w);
+}
+
+void PC::prolong_block(const double* WL, double* Y, int w, double* ye) {
+  const int nown = n_owned();
+  if (size == 1) {
+    bk::segsum_rows(Y, WL, d_rt_ptr, d_rt_idx, nown, w, false);
+    return;
+  }
+  bk::segsum_rows(ye, WL, d_rt_ptr, d_rt_idx, nE, w, false);
+  bk::copy(comm_send, ye + (int64_t)nown * w, (int)((int64_t)nH * w));
+  if (cb_exchange(cb_user, 1 | (w << 1))) throw std::runtime_error("GenEO: halo exchange callback failed");
+  bk::copy(Y, ye, (int)((int64_t)nown * w));
+  bk::segsum_rows(Y, comm_recv, d_rv_ptr, d_rv_idx, nown, w, true);
+}
+
+void PC::matmult_block(const double* X, double* Y, int w, double* WL, double* xe) {
+  info.spmv_calls += w;
+  if (size == 1) {
+    bk::spmm_strided(neuE, X, w, WL, w, w, nullptr, nullptr);
+  } else {
+    const int nown = n_owned();
+    bk::gather_rows(comm_send, X, d_send_idx, (int)send_idx.size(), w);
+    if (cb_exchange(cb_user, 0 | (w << 1))) throw std::runtime_error("GenEO: halo exchange callback failed");
+    bk::copy(xe, X, (int)((int64_t)nown * w));
+    bk::copy(xe + (int64_t)nown * w, comm_recv, (int)((int64_t)nH * w));
+    bk::spmm_strided(neuE, xe, w, WL, w, w, nullptr, nullptr);
+  }
+  prolong_block(WL, Y, w, xe);
+}
+
 // [D] M^-1 [D] on the concatenated local space: one independent Jacobi-PCG per subdomain,
 // all subdomains advanced by the same launches (geneo.cpp:1991-2002 with MUMPS replaced).
 void PC::local_solve(double* wL) {
@@ -1806,10 +1850,53 @@ int PC::build_E() {
   bk::h2d(d_zoff, zoff.data(), sizeof(int) * ns);
   d_yE = (double*)bk::alloc(sizeof(double) * std::max(1, dimE));
   h_yE.assign(std::max(1, dimE), 0.0);
-  // column j of E: Z^T A (Z e_j)
   E.assign((size_t)dimE * dimE, 0.0);
-  std::vector<double> unit(dimE, 0.0), colv(dimE);
   const int nown = n_owned();
+  const int W = std::min(32, size == 1 ? 32 : comm_width);
+  if (W >= 8 && dimE > 0 && !getenv("GENEO_E_COLUMNWISE")) {
+    // Blocked assembly: W columns of E per pass, 4 wide halo exchanges per pass instead of 4 per column.
+    //   WL = ZR C_j (selection of W coarse vectors, MFMA block kernel) ; T1 = sum R^T WL ; T2 = A T1 ;
+    //   XL = R T2 ; G_s = ZR_s^T XL_s (MFMA Gram) = the rows of E owned by subdomain s, columns of the pass
+    const int kp = ((std::max(1, kmax) + 15) / 16) * 16;
+    auto dv = [](size_t n) { return (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, n)); };
+    double* ZR = dv((size_t)nL * kp);
+    double *WLb = dv((size_t)nL * W), *XLb = dv((size_t)nL * W);
+    double *T1 = dv((size_t)nown * W), *T2 = dv((size_t)nown * W);
+    double* xe = dv((size_t)std::max(nE, nown) * W);
+    double *dC = dv((size_t)ns * kp * W), *dG = dv((size_t)ns * kp * W);
+    std::vector<double> hC((size_t)ns * kp * W), hG((size_t)ns * kp * W);
+    bk::z_rowmajor(ch, d_Z, d_zbase, d_ksub, ZR, kp);
+    int rc = 0;
+    for (int j0 = 0; j0 < dimE && !rc; j0 += W) {
+      std::fill(hC.begin(), hC.end(), 0.0);
+      for (int s = 0; s < ns; ++s)
+        for (int k = 0; k < ksub[s]; ++k) {
+          const int c = zoff[s] + k - j0;
+          if (c >= 0 && c < W) hC[((size_t)s * kp + k) * W + c] = 1.0;
+        }
+      bk::h2d(dC, hC.data(), sizeof(double) * hC.size());
+      bk::block_mul(ch, ZR, kp, kp, dC, W, WLb, W, false);
+      prolong_block(WLb, T1, W, xe);
+      matmult_block(T1, T2, W, WLb, xe);
+      restrict_block(T2, XLb, W, xe);
+      bk::gram(ch, ZR, kp, kp, XLb, W, W, dG);
+      bk::d2h(hG.data(), dG, sizeof(double) * hG.size());
+      for (int s = 0; s < ns; ++s)
+        for (int k = 0; k < ksub[s]; ++k)
+          for (int c = 0; c < W && j0 + c < dimE; ++c)
+            E[(size_t)(zoff[s] + k) * dimE + j0 + c] = hG[((size_t)s * kp + k) * W + c];
+    }
+    for (double* p : {ZR, WLb, XLb, T1, T2, xe, dC, dG}) bk::dfree(p);
+    if (size > 1) {  // rows of E live with the rank of their subdomain: one sum over the ranks
+      double* dE = dv(E.size());
+      bk::h2d(dE, E.data(), sizeof(double) * E.size());
+      allreduce(dE, (int)E.size());
+      bk::d2h(E.data(), dE, sizeof(double) * E.size());
+      bk::dfree(dE);
+    }
+  } else {
+  // column j of E: Z^T A (Z e_j)
+  std::vector<double> unit(dimE, 0.0), colv(dimE);
   for (int j = 0; j < dimE; ++j) {
     unit[j] = 1.0;
     bk::h2d(d_yE, unit.data(), sizeof(double) * dimE);
@@ -1822,6 +1909,7 @@ int PC::build_E() {
     allreduce(d_yE, dimE);
     bk::d2h(colv.data(), d_yE, sizeof(double) * dimE);
     for (int i = 0; i < dimE; ++i) E[(size_t)i * dimE + j] = colv[i];
+  }
   }
   (void)nown;
   Efac = E;

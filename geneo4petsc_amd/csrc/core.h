@@ -105,6 +105,7 @@ class PC {
   void* cb_user = nullptr;
   double *comm_send = nullptr, *comm_recv = nullptr, *comm_red = nullptr;  // device buffers owned by the caller
   int comm_red_cap = 0;
+  int comm_width = 1;        // the halo buffers hold this many vectors per exchange (PCGenEOSetCommWidth)
 
   PC();
   ~PC();
@@ -188,6 +189,9 @@ class PC {
   int build_E();
   void restrict_to_local(const double* x_owned, double* xL);      // R  (applyLevel1Scatter)
   void prolong_add(const double* wL, double* y_owned);            // sum R^T (applyLevel1Gather)
+  void restrict_block(const double* X, double* XL, int w, double* xe);
+  void prolong_block(const double* WL, double* Y, int w, double* ye);
+  void matmult_block(const double* X, double* Y, int w, double* WL, double* xe);
   void local_solve(double* wL);                                   // [D] M^-1 [D]
   void coarse_solve_local(const double* xL, double* yE);          // yE = E^-1 Z^T x (from xL)
   void allreduce(double* dev, int n);

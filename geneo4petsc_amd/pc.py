@@ -176,6 +176,10 @@ class GenEOPC:
         self.n_owned = len(owned_gid)
         self.rank = int(rank)
 
+    def set_comm_width(self, width):
+        """The halo buffers hold `width` vectors per exchange (PCGenEOSetCommWidth): blocked assembly of E."""
+        self._chk(self.lib.PCGenEOSetCommWidth(self.h, int(width)))
+
     # -- PC ops ------------------------------------------------------------------------------
     def setup(self, b=None):
         """KSPSetUp -> setUpGenEOPC.  b: DeviceVector / numpy (needed only for the E-hybrid initial guess)."""

@@ -116,6 +116,11 @@ PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int*
                               const int* halo_gid, const int* recv_counts, const int* send_counts,
                               const int* send_idx, GeneoExchangeFn exchange, GeneoAllreduceFn allreduce,
                               void* user, double* send_dev, double* recv_dev, double* red_dev, int red_capacity);
+/* Optional: send_dev / recv_dev hold max_width x the single-vector counts (entry-major, the vectors of one entry
+ * contiguous) and the exchange callback honours the width passed in the upper bits of its flag
+ * (flag = reverse | width << 1; width 0 means 1).  Lets the coarse operator E be assembled 32 columns per
+ * exchange instead of one.  Default width 1. */
+PetscErrorCode PCGenEOSetCommWidth(PC pc, int max_width);
 
 /* ---- PC operations (the PETSc ops table, src/geneo.cpp:2717-2720) ------------------------- */
 PetscErrorCode PCSetUp_GenEO(PC pc);                                   /* setUpGenEOPC :1672 */

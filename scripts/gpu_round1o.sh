@@ -1,0 +1,22 @@
+#!/bin/bash
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=5 > $O/gpu_all_o.log 2>&1
+rc=$?; echo "pytest gpu exit $rc"; tail -4 $O/gpu_all_o.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 400 python bench.py --no-cpu-baseline > $O/bench_o.log 2>&1
+rc=$?; echo "bench exit $rc"; tail -1 $O/bench_o.log | cut -c1-1800
+[ $rc -eq 0 ] || exit $rc
+export GENEO_BENCH_COMM=staged MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=2
+for N in 2 4; do
+  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2956$N \
+     bench.py --gpus $N --steps 1 --warmup 1 --n-per-gpu 64 --no-cpu-baseline > $O/bench_staged_o_n$N.log 2>&1
+  rc=$?; echo "bench staged N=$N exit $rc"; tail -1 $O/bench_staged_o_n$N.log | python -c "
+import sys, json
+j=json.loads(sys.stdin.read()); print(j['n_gpus'], 'setup', j['setup_s'], j['setup_breakdown_s'], 'solve', j['solve_s'], 'its', j['iterations'], 'dimE', j['dimE'])"
+  [ $rc -eq 0 ] || exit $rc
+done

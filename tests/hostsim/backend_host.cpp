@@ -103,6 +103,26 @@ void csr_diag(const Csr& a, double* d) {
   }
 }
 void gather(double* out, const double* in, const int* idx, int n) { for (int i = 0; i < n; ++i) out[i] = in[idx[i]]; }
+void gather_rows(double* out, const double* in, const int* idx, int n, int w) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < w; ++j) out[(int64_t)i * w + j] = in[(int64_t)idx[i] * w + j];
+}
+void segsum_rows(double* out, const double* in, const int* ptr, const int* idx, int nseg, int w, bool accumulate) {
+  for (int e = 0; e < nseg; ++e)
+    for (int j = 0; j < w; ++j) {
+      double s = 0;
+      for (int k = ptr[e]; k < ptr[e + 1]; ++k) s += in[(int64_t)idx[k] * w + j];
+      out[(int64_t)e * w + j] = accumulate ? out[(int64_t)e * w + j] + s : s;
+    }
+}
+void z_rowmajor(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, double* ZR, int kp) {
+  for (int s = 0; s < c.nsub; ++s) {
+    const int ns = c.suboff[s + 1] - c.suboff[s];
+    for (int i = 0; i < ns; ++i)
+      for (int j = 0; j < kp; ++j)
+        ZR[(int64_t)(c.suboff[s] + i) * kp + j] = j < ksub[s] ? Z[zbase[s] + (int64_t)j * ns + i] : 0.0;
+  }
+}
 void gather_mul(double* out, const double* in, const int* idx, const double* d, int n) {
   for (int i = 0; i < n; ++i) out[i] = in[idx[i]] * d[i];
 }

@@ -203,3 +203,21 @@ def test_no_cut_keeps_every_eigenvalue_below_tau(lib):
     _, info = cases.compare_with_oracle(lib, 10, (2, 2, 2), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.42", "-ksp_type", "cg"] + TIGHT)
     assert info["dimE"] == 276
     cases.compare_with_oracle(lib, 6, (2, 1, 1), 1, ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.3", "-ksp_type", "cg"] + TIGHT)
+
+
+def test_E_blocked_and_columnwise_assembly_agree(lib, monkeypatch):
+    """E = Z^T A Z: 32 columns per pass (MFMA block kernels, wide halo exchanges) vs one column per pass (hosts
+    whose transport holds one vector per exchange, PCGenEOSetCommWidth not called)."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8"] + TIGHT
+    mesh, dec, a, b = cases.grid_case(10, 3, (2, 2, 2), 1)
+    pc = cases.run_pc(lib, mesh, dec, argv, b)
+    e_blocked = pc.E().copy()
+    pc.destroy()
+    monkeypatch.setenv("GENEO_E_COLUMNWISE", "1")
+    pc = cases.run_pc(lib, mesh, dec, argv, b)
+    e_col = pc.E().copy()
+    pc.destroy()
+    orc = cases.oracle_for(mesh, dec, argv, b)
+    assert e_blocked.shape == e_col.shape == orc.E.shape
+    np.testing.assert_allclose(e_blocked, e_col, rtol=1e-11, atol=1e-12 * np.abs(e_col).max())
+    np.testing.assert_allclose(np.linalg.eigvalsh(0.5 * (e_blocked + e_blocked.T)), np.linalg.eigvalsh(orc.E), rtol=1e-8)
