@@ -15,6 +15,46 @@
 namespace geneo {
 
 // ------------------------------------------------------------------------------ host sparse kernels
+// f(t, r0, r1) over contiguous row ranges on up to 16 host threads (serial below 20000 rows)
+static void parallel_rows(int n, const std::function<void(int, int)>& f) {
+  int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  if (n < 20000) nth = 1;
+  if (nth == 1) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() { f((int)((int64_t)n * t / nth), (int)((int64_t)n * (t + 1) / nth)); });
+  for (auto& x : th) x.join();
+}
+
+// Transpose of a matrix whose rows [rs[b], rs[b+1]) only reference columns [cs[b], cs[b+1]) (the transfer operators
+// are block diagonal by subdomain): the blocks are transposed independently on host threads.
+static HostCsr transpose_blocks(const HostCsr& a, int ncols, const std::vector<int>& rs, const std::vector<int>& cs) {
+  HostCsr t;
+  t.n = ncols;
+  t.rowptr.assign(ncols + 1, 0);
+  for (int c : a.col) t.rowptr[c + 1]++;
+  for (int i = 0; i < ncols; ++i) t.rowptr[i + 1] += t.rowptr[i];
+  t.col.resize(a.col.size());
+  t.val.resize(a.val.size());
+  const int nb = (int)rs.size() - 1;
+  auto one = [&](int b) {
+    std::vector<int> fill(t.rowptr.begin() + cs[b], t.rowptr.begin() + cs[b + 1]);
+    for (int i = rs[b]; i < rs[b + 1]; ++i)
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int p = fill[a.col[k] - cs[b]]++;
+        t.col[p] = i;
+        t.val[p] = a.val[k];
+      }
+  };
+  std::vector<std::thread> th;
+  for (int b = 0; b < nb; ++b) th.emplace_back(one, b);
+  for (auto& x : th) x.join();
+  return t;
+}
+
 static HostCsr transpose(const HostCsr& a, int ncols) {
   HostCsr t;
   t.n = ncols;
@@ -197,30 +237,35 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     HostCsr P;
     P.n = n;
     P.rowptr.assign(n + 1, 0);
-    for (int i = 0; i < n; ++i) {  // row sizes: the entries of A*P0 plus the tentative one if absent
-      bool has = false;
-      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k)
-        if (AP0.col[k] == agg[i]) has = true;
-      P.rowptr[i + 1] = P.rowptr[i] + (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
-    }
+    parallel_rows(n, [&](int r0, int r1) {  // row sizes: the entries of A*P0 plus the tentative one if absent
+      for (int i = r0; i < r1; ++i) {
+        bool has = false;
+        for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k)
+          if (AP0.col[k] == agg[i]) has = true;
+        P.rowptr[i + 1] = (AP0.rowptr[i + 1] - AP0.rowptr[i]) + (has ? 0 : 1);
+      }
+    });
+    for (int i = 0; i < n; ++i) P.rowptr[i + 1] += P.rowptr[i];
     P.col.resize(P.rowptr[n]);
     P.val.resize(P.rowptr[n]);
-    for (int i = 0; i < n; ++i) {
-      int q = P.rowptr[i];
-      bool has = false;
-      for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k, ++q) {
-        double v = -omega * L.dinv[i] * AP0.val[k];
-        if (AP0.col[k] == agg[i]) { v += 1.0; has = true; }
-        P.col[q] = AP0.col[k];
-        P.val[q] = v;
+    parallel_rows(n, [&](int r0, int r1) {
+      for (int i = r0; i < r1; ++i) {
+        int q = P.rowptr[i];
+        bool has = false;
+        for (int k = AP0.rowptr[i]; k < AP0.rowptr[i + 1]; ++k, ++q) {
+          double v = -omega * L.dinv[i] * AP0.val[k];
+          if (AP0.col[k] == agg[i]) { v += 1.0; has = true; }
+          P.col[q] = AP0.col[k];
+          P.val[q] = v;
+        }
+        if (!has) {
+          P.col[q] = agg[i];
+          P.val[q] = 1.0;
+        }
       }
-      if (!has) {
-        P.col[q] = agg[i];
-        P.val[q] = 1.0;
-      }
-    }
+    });
     auto t_3 = tnow();
-    HostCsr R = transpose(P, nc);
+    HostCsr R = (nsub > 1 && n >= 20000) ? transpose_blocks(P, nc, L.suboff, csub) : transpose(P, nc);
     auto t_4 = tnow();
     HostCsr AP = spgemm(L.A, P, nc);
     auto t_5 = tnow();

@@ -794,7 +794,7 @@ void PC::local_solve(double* wL) {
     }
   };
   const bool graphable = (check % 2 == 0);
-  if (graphable && !cg_graph && !cg_graph_failed) {
+  if (graphable && !cg_graph && !cg_graph_failed && !bk::spmv_profiling()) {
     if (bk::graph_capture_begin()) {
       chunk();
       cg_graph = bk::graph_capture_end();
@@ -803,10 +803,10 @@ void PC::local_solve(double* wL) {
     if (!cg_graph) cg_graph_failed = true;
   }
   while (!done && it < opt.dls1_max_it) {
-    // while the in-situ SpMV timer runs, one chunk in eight goes out as direct launches: HIP events cannot
-    // bracket kernels inside a replayed graph, and the sampled launches are the very same kernels
-    const bool direct = bk::spmv_profiling() && (cg_chunks++ % 8 == 0);
-    if (graphable && cg_graph && !direct) bk::graph_launch(cg_graph);
+    // While the in-situ SpMV timer runs (bench.py) the chunk goes out as direct launches: HIP events cannot
+    // bracket kernels inside a replayed graph (hipEventElapsedTime rejects events recorded by graph nodes),
+    // and the timer must see every fine-level launch, not a biased subset.
+    if (graphable && cg_graph && !bk::spmv_profiling()) bk::graph_launch(cg_graph);
     else chunk();
     it += check;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);

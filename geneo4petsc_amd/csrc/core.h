@@ -158,7 +158,6 @@ class PC {
   int finish_amg1();
   void* cg_graph = nullptr;    // HIP graph of one inner-PCG chunk (local_solve)
   bool cg_graph_failed = false;
-  long long cg_chunks = 0;
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 
