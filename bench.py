@@ -134,7 +134,9 @@ def main():
     ap.add_argument("--cut", type=int, default=20)
     ap.add_argument("--eps-tol", type=float, default=1e-3, help="reference default, geneo.cpp:658")
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc KSP default rtol")
-    ap.add_argument("--dls1-rtol", type=float, default=1e-10)
+    ap.add_argument("--dls1-rtol", type=float, default=1e-6,
+                    help="relative tolerance of the inner (local) solves; 1e-6 leaves the outer PCG untouched at rtol 1e-5 "
+                         "(23 iterations and true residual 1.7814e-3 with 1e-6, 1e-8 and 1e-10 alike; 25 iterations with 1e-4)")
     ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
     ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
     ap.add_argument("--cpu-sample-n", type=int, default=32)
@@ -226,7 +228,20 @@ def main():
     # needs direct launches: HIP events cannot bracket kernels inside a graph), which is how the library runs
     # outside this benchmark.  Reported as information only.
     pcs[-2].destroy()
-    _, _, ginfo = step(pcs[-1])
+    pcs[-1].setup(bd)
+    xg, gits, _, greason = pcs[-1].solve(bd)
+    ginfo = pcs[-1].info()
+    # true residual || A x - b || / || b || of that solve (driver:1072-1087), owned rows, summed over the ranks
+    axg = pcs[-1].matmult(xg)
+    rr = axg.to_host() - b
+    num, den = float(rr @ rr), float(b @ b)
+    xg.free()
+    axg.free()
+    if dist is not None:
+        tt = torch.tensor([num, den], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tt)
+        num, den = float(tt[0]), float(tt[1])
+    true_res = (num / den) ** 0.5
     barrier()
     pc = pcs[-1]
     local = {"elapsed": elapsed, "spmv_ms": ms_sum.value, "spmv_bytes": by_sum.value, "setup": info["setupTime"],
@@ -273,7 +288,8 @@ def main():
             "setup_breakdown_s": {"level1_upload_and_amg": info["lvl1SetupMinvTimeLoc"],
                                   "eigensolve_lobpcg": info["lvl2SetupEigTimeLoc"],
                                   "coarse_operator_E": info["lvl2SetupETimeLoc"]},
-            "untimed_step_with_hip_graphs_s": {"setup": ginfo["setupTime"], "solve": ginfo["solveTime"]},
+            "untimed_step_with_hip_graphs_s": {"setup": ginfo["setupTime"], "solve": ginfo["solveTime"],
+                                               "iterations": gits, "true_residual": true_res},
             "solve_breakdown_s": {"local_solves": info["lvl1ApplyMinvTimeLoc"], "coarse_Zt": info["lvl2ApplyZtTimeLoc"],
                                   "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
             "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
