@@ -81,10 +81,19 @@ static HostCsr spgemm(const HostCsr& a, const HostCsr& b, int ncols_b) {
   c.n = n;
   c.rowptr.assign(n + 1, 0);
   int nth = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-  if (n < 20000) nth = 1;
+  if (a.col.size() < 200000) nth = 1;   // by work, not by rows: a restriction operator has few, long rows
+  nth = std::max(1, std::min(nth, n));
+  // contiguous row ranges of (about) equal nnz
+  std::vector<int> cut(nth + 1, n);
+  cut[0] = 0;
+  for (int t = 1; t < nth; ++t) {
+    const int64_t target = (int64_t)a.rowptr[n] * t / nth;
+    cut[t] = (int)(std::lower_bound(a.rowptr.begin(), a.rowptr.begin() + n + 1, (int)target) - a.rowptr.begin());
+    cut[t] = std::min(n, std::max(cut[t], cut[t - 1]));
+  }
   auto range = [&](int t, int& r0, int& r1) {
-    r0 = (int)((int64_t)n * t / nth);
-    r1 = (int)((int64_t)n * (t + 1) / nth);
+    r0 = cut[t];
+    r1 = cut[t + 1];
   };
   auto run = [&](const std::function<void(int)>& f) {
     if (nth == 1) { f(0); return; }
