@@ -1241,6 +1241,12 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
         fprintf(stderr, " %.2e", mx);
       }
+      fprintf(stderr, " | locked");
+      for (int s = 0; s < ns; ++s) {
+        int nl = 0;
+        for (int j = 0; j < m; ++j) nl += locked[(size_t)s * m + j] ? 1 : 0;
+        fprintf(stderr, " %d", nl);
+      }
       fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
     }
     if (all_done || it == opt.eps_max_it) break;
