@@ -118,7 +118,8 @@ def cpu_baseline(args, doms):
 def geneo_argv(args):
     return ["-geneo_lvl", args.lvl, "-geneo_tau", str(args.tau), "-geneo_cut", str(args.cut),
             "-els2_eps_tol", str(args.eps_tol), "-ksp_type", "cg", "-ksp_rtol", str(args.rtol),
-            "-dls1_ksp_rtol", str(args.dls1_rtol), "-dls1_pc_type", args.dls1_pc, "-els2_pc_type", args.els2_pc]
+            "-dls1_ksp_rtol", str(args.dls1_rtol), "-dls1_pc_type", args.dls1_pc, "-els2_pc_type", args.els2_pc] \
+        + args.pc_args.split()
 
 
 def main():
@@ -139,6 +140,7 @@ def main():
                          "(23 iterations and true residual 1.7814e-3 with 1e-6, 1e-8 and 1e-10 alike; 25 iterations with 1e-4)")
     ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
     ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
+    ap.add_argument("--pc-args", default="", help="further options for the PC, e.g. '-els2_amg_plain 1'")
     ap.add_argument("--cpu-sample-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
