@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -182,16 +183,32 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
 
 static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
   dinv.assign(a.n, 1.0);
-  double rho = 0.0;
-  for (int i = 0; i < a.n; ++i) {
-    double d = 0.0, row = 0.0;
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
-      row += std::fabs(a.val[k]);
-      if (a.col[k] == i) d += a.val[k];
+  std::vector<double> part(64, 0.0);
+  std::vector<char> bad(64, 0);
+  int slot = 0;
+  std::mutex mu;
+  parallel_rows(a.n, [&](int r0, int r1) {
+    double rho = 0.0;
+    bool neg = false;
+    for (int i = r0; i < r1; ++i) {
+      double d = 0.0, row = 0.0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        row += std::fabs(a.val[k]);
+        if (a.col[k] == i) d += a.val[k];
+      }
+      if (!(d > 0.0)) { neg = true; continue; }
+      dinv[i] = 1.0 / d;
+      rho = std::max(rho, row / d);
     }
-    if (!(d > 0.0)) throw std::runtime_error("AMG: non-positive diagonal");
-    dinv[i] = 1.0 / d;
-    rho = std::max(rho, row / d);
+    std::lock_guard<std::mutex> lk(mu);
+    part[slot] = rho;
+    bad[slot] = neg;
+    ++slot;
+  });
+  double rho = 0.0;
+  for (int t = 0; t < slot; ++t) {
+    if (bad[t]) throw std::runtime_error("AMG: non-positive diagonal");
+    rho = std::max(rho, part[t]);
   }
   return rho > 0 ? rho : 2.0;
 }
@@ -202,11 +219,13 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
   levels.clear();
   const int nsub = (int)suboff.size() - 1;
   levels.emplace_back();
-  levels.back().A = A;
+  levels.back().n = A.n;
+  levels.back().nnz = A.val.size();
   levels.back().suboff = suboff;
   while (true) {
     AmgLevelHost& L = levels.back();
-    L.rho = gershgorin_rho(L.A, L.dinv);
+    const HostCsr& LA = (levels.size() == 1) ? A : L.A;   // level 0: the caller's matrix, not a copy
+    L.rho = gershgorin_rho(LA, L.dinv);
     int maxblk = 0;
     for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, L.suboff[s + 1] - L.suboff[s]);
     if (maxblk <= prm.coarse_size || (int)levels.size() >= prm.max_levels) break;
@@ -217,13 +236,13 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
       return std::chrono::duration<double>(b - a).count();
     };
     auto t_0 = tnow();
-    const int n = L.A.n;
+    const int n = LA.n;
     std::vector<int> agg(n, -1), csub(nsub + 1, 0);
     {  // the diagonal blocks are independent: one host thread per subdomain
       std::vector<int> nagg(nsub, 0);
       std::vector<std::thread> th;
       for (int s = 0; s < nsub; ++s)
-        th.emplace_back([&, s]() { nagg[s] = aggregate_block(L.A, L.suboff[s], L.suboff[s + 1], agg); });
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(LA, L.suboff[s], L.suboff[s + 1], agg); });
       for (auto& x : th) x.join();
       for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
       for (int s = 0; s < nsub; ++s)
@@ -241,7 +260,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     for (int i = 0; i < n; ++i) P0.col[i] = agg[i];
     const double omega = 4.0 / (3.0 * L.rho);
     auto t_1 = tnow();
-    HostCsr AP0 = spgemm(L.A, P0, nc);
+    HostCsr AP0 = spgemm(LA, P0, nc);
     auto t_2 = tnow();
     HostCsr P;
     P.n = n;
@@ -276,22 +295,25 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     auto t_3 = tnow();
     HostCsr R = (nsub > 1 && n >= 20000) ? transpose_blocks(P, nc, L.suboff, csub) : transpose(P, nc);
     auto t_4 = tnow();
-    HostCsr AP = spgemm(L.A, P, nc);
+    HostCsr AP = spgemm(LA, P, nc);
     auto t_5 = tnow();
     HostCsr Ac = spgemm(R, AP, nc);
     auto t_6 = tnow();
     if (dbg)
       fprintf(stderr, "[amg] level n %d -> %d nnz %zu -> %zu | agg %.3f AP0 %.3f P %.3f Rt %.3f AP %.3f RAP %.3f s\n", n, nc,
-              L.A.val.size(), Ac.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, t_3), tsec(t_3, t_4),
+              LA.val.size(), Ac.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, t_3), tsec(t_3, t_4),
               tsec(t_4, t_5), tsec(t_5, t_6));
     L.P = std::move(P);
     L.R = std::move(R);
     levels.emplace_back();
+    levels.back().n = Ac.n;
+    levels.back().nnz = Ac.val.size();
     levels.back().A = std::move(Ac);
     levels.back().suboff = csub;
   }
   // dense inverse of every coarsest block (SPD: Cholesky; tiny pivots regularised)
   const AmgLevelHost& C = levels.back();
+  const HostCsr& CA = (levels.size() == 1) ? A : C.A;   // a single level: the caller's matrix is the coarsest one
   coarse_base.assign(nsub + 1, 0);
   for (int s = 0; s < nsub; ++s) {
     const int64_t m = C.suboff[s + 1] - C.suboff[s];
@@ -303,7 +325,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     if (m == 0) return;
     std::vector<double> a((size_t)m * m, 0.0);
     for (int i = 0; i < m; ++i)
-      for (int k = C.A.rowptr[r0 + i]; k < C.A.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (C.A.col[k] - r0)] += C.A.val[k];
+      for (int k = CA.rowptr[r0 + i]; k < CA.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (CA.col[k] - r0)] += CA.val[k];
     for (int i = 0; i < m; ++i)
       for (int j = i + 1; j < m; ++j) a[(size_t)i * m + j] = a[(size_t)j * m + i] = 0.5 * (a[(size_t)i * m + j] + a[(size_t)j * m + i]);
     std::vector<double> l = a;
@@ -361,12 +383,13 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
   for (size_t l = 0; l < levels.size(); ++l) {
     const AmgLevelHost& H = levels[l];
     Lvl L;
-    L.n = H.A.n;
+    L.n = H.n;
     L.rho = H.rho;
     if (l == 0 && fine_dev) {
       L.A = *fine_dev;
       L.own_A = false;
     } else {
+      if (l == 0) throw std::runtime_error("AMG: the level-0 matrix must already be resident (fine_dev)");
       L.A = bk::csr_upload(H.A.n, H.A.rowptr.data(), H.A.col.data(), H.A.val.data());
     }
     if (l + 1 < levels.size()) {
@@ -384,8 +407,8 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
       L.x = (double*)bk::alloc(blk);
     }
     L.fused = bk::csr_fusable(L.A) && (l + 1 == (int)levels.size() || bk::csr_fusable(L.P)) && !getenv("GENEO_AMG_UNFUSED");
-    if (l == 0) nnz0 = (double)H.A.val.size();
-    nnzt += (double)H.A.val.size();
+    if (l == 0) nnz0 = (double)H.nnz;
+    nnzt += (double)H.nnz;
     lv.push_back(L);
   }
   opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;

@@ -21,7 +21,9 @@ struct AmgParams {
 };
 
 struct AmgLevelHost {
-  HostCsr A, P, R;            // P: n x nc, R = P^T
+  HostCsr A, P, R;            // P: n x nc, R = P^T.  Level 0 borrows the caller's matrix: A stays empty there
+  int n = 0;                  // rows of this level
+  size_t nnz = 0;
   std::vector<double> dinv;
   std::vector<int> suboff;    // nsub+1 row offsets of the subdomain blocks on this level
   double rho = 2.0;           // Gershgorin bound of D^-1 A

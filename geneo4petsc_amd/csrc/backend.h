@@ -53,6 +53,8 @@ struct Csr {
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 void csr_free(Csr& a);
+// same matrix with every column index c replaced by map_dev[c] (device-side copy: no host round trip)
+Csr  csr_remap_columns(const Csr& a, const int* map_dev);
 void spmv(const Csr& a, const double* x, double* y);                    // y = A x
 // In-situ timing of the SpMV launches issued between start and stop: every `every`-th launch is
 // bracketed by two HIP events on the backend stream (no host sync until stop).

@@ -254,6 +254,31 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   }
   return a;
 }
+__global__ void k_map_int(int* __restrict__ out, const int* __restrict__ in, const int* __restrict__ map, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = map[in[i]];
+}
+Csr csr_remap_columns(const Csr& a, const int* map_dev) {
+  Csr b = a;   // scalars (n, nnz, nslice, nlong, max_row, vec_lpr, ...) carry over; the arrays are re-made below
+  auto dup = [](const void* src, size_t bytes) -> void* {
+    void* p = alloc(std::max<size_t>(bytes, 8));
+    if (src && bytes) d2d(p, src, bytes);
+    return p;
+  };
+  const size_t nnz = (size_t)a.nnz;
+  b.rowptr = (int*)dup(a.rowptr, sizeof(int) * ((size_t)a.n + 1));
+  b.val = (double*)dup(a.val, sizeof(double) * nnz);
+  b.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, nnz));
+  if (nnz) hipLaunchKernelGGL(k_map_int, dim3(gridv((int64_t)nnz)), dim3(256), 0, g_stream, b.col, a.col, map_dev, (int64_t)nnz);
+  b.rowblk = a.rowblk ? (int*)dup(a.rowblk, sizeof(int) * ((size_t)a.nblk + 1)) : nullptr;
+  b.sl_ptr = (int64_t*)dup(a.sl_ptr, sizeof(int64_t) * ((size_t)a.nslice + 1));
+  b.sl_val = (double*)dup(a.sl_val, sizeof(double) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+  b.sl_col = (int*)alloc(sizeof(int) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+  if (a.sl_nnz > 0)
+    hipLaunchKernelGGL(k_map_int, dim3(gridv(a.sl_nnz)), dim3(256), 0, g_stream, b.sl_col, a.sl_col, map_dev, a.sl_nnz);
+  b.long_rows = (int*)dup(a.long_rows, sizeof(int) * std::max<size_t>(1, (size_t)a.nlong));
+  return b;
+}
 void csr_free(Csr& a) {
   dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
   dfree(a.sl_ptr); dfree(a.sl_col); dfree(a.sl_val); dfree(a.long_rows);

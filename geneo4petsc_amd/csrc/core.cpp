@@ -521,12 +521,33 @@ int PC::setup(const double* b_dev) {
   }
   auto t1 = clk::now();
   HostCsr h_neuL = make_blockdiag(neu, suboff, nullptr);
+  // The eigensolve waits for the A_Neu hierarchy: its host set-up starts NOW on its own thread and the
+  // uploads / sliced-layout builds / diagonals below overlap it.
+  const bool want1 = (opt.dls1_pc == "amg");
+  const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
+  const AmgParams ap = amg_params(opt);
+  AmgHostResult rN;
+  std::thread thN;
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joinN{thN};
+  if (wantN)
+    thN = std::thread([&h_neuL, &rN, ap, this]() {
+      auto t0 = clk::now();
+      try {
+        amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
+      } catch (std::exception& e) {
+        rN.err = e.what();
+      }
+      rN.secs = secs(t0, clk::now());
+    });
   neuL = upload_host(h_neuL);
-  {  // same matrix with ext-space columns for the MATIS MatMult (own copy: the sliced layout embeds the columns)
-    std::vector<int> l2e(nL);
-    bk::d2h(l2e.data(), d_l2e, sizeof(int) * nL);
-    neuE = upload_blockdiag(neu, suboff, l2e.data());
-  }
+  // same matrix with ext-space columns (l2e o col) for the MATIS MatMult, so that the gather R x is fused into the
+  // SpMV; own copy (the sliced layout embeds the columns), made on the device from the one just uploaded
+  neuE = bk::csr_remap_columns(neuL, d_l2e);
   HostCsr h_dirL = make_blockdiag(lvl1, suboff, nullptr);
   dirL = upload_host(h_dirL);
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
@@ -583,9 +604,6 @@ int PC::setup(const double* b_dev) {
     // then A_Dir / A_Rob (local solves), whose host set-up runs on its own thread WHILE the GPU is busy
     // with the eigensolve; it is joined and uploaded when level 2 is done (or right away without level 2).
     auto ta = clk::now();
-    const bool want1 = (opt.dls1_pc == "amg");
-    const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
-    const AmgParams ap = amg_params(opt);
     pend1.reset(want1 ? new Amg1Pending() : nullptr);
     if (want1) pend1->mat = std::move(h_dirL);
     const bool overlap1 = want1 && wantN && !getenv("GENEO_AMG_NO_OVERLAP");
@@ -603,16 +621,7 @@ int PC::setup(const double* b_dev) {
       });
     };
     if (want1 && !overlap1) start1();
-    AmgHostResult rN;
-    if (wantN) {
-      auto t0 = clk::now();
-      try {
-        amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
-      } catch (std::exception& e) {
-        rN.err = e.what();
-      }
-      rN.secs = secs(t0, clk::now());
-    }
+    if (thN.joinable()) thN.join();
     if (overlap1) start1();
     if (!rN.err.empty()) return fail(rN.err);
     try {
@@ -628,7 +637,9 @@ int PC::setup(const double* b_dev) {
     }
     bk::sync();
     info.amgSetupTime = secs(ta, clk::now());
-    if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] A_Neu host set-up %.3f s, with upload %.3f s\n", rN.secs, info.amgSetupTime);
+    if (getenv("GENEO_DEBUG"))
+      fprintf(stderr, "[amg] A_Neu host set-up %.3f s (started %.3f s before this point), waited + upload %.3f s\n", rN.secs,
+              secs(t1, ta), info.amgSetupTime);
     if (want1 && !opt.lvl2)
       if (int rc = finish_amg1()) return rc;
   }

@@ -42,6 +42,11 @@ Csr csr_upload(int n, const int* rp, const int* col, const double* val) {
   for (int i = 0; i < n; ++i) a.max_row = std::max(a.max_row, rp[i + 1] - rp[i]);
   return a;
 }
+Csr csr_remap_columns(const Csr& a, const int* map) {
+  Csr b = csr_upload(a.n, a.rowptr, a.col, a.val);
+  for (int64_t k = 0; k < a.nnz; ++k) b.col[k] = map[a.col[k]];
+  return b;
+}
 void csr_free(Csr& a) { dfree(a.rowptr); dfree(a.col); dfree(a.val); a = Csr(); }
 void spmv(const Csr& a, const double* x, double* y) {
   for (int i = 0; i < a.n; ++i) {
