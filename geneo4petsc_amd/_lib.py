@@ -84,6 +84,8 @@ SYMBOLS = {
     "PCGenEOSetIntersect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p]),
     "GeneoGetLibInput": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GeneoInput)]),
     "GeneoFreeInput": (None, [C.POINTER(GeneoInput)]),
+    "GeneoTestSparseProduct": (C.c_longlong, [C.c_int, C.POINTER(GeneoCsr), C.POINTER(GeneoCsr), C.c_int, c_int_p, c_int_p, c_dbl_p,
+                               C.c_longlong]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
     "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),

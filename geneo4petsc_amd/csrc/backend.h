@@ -53,6 +53,18 @@ struct Csr {
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 void csr_free(Csr& a);
+// ---- sparse products on the device (multigrid set-up: Galerkin products without a host round trip) ----------------
+// C = A B (B has ncols_b columns) and A^T (A has ncols columns).  Columns come out sorted inside every row and
+// every sum runs in a fixed order: results are bitwise reproducible.  ok = false: a row exceeded the kernels'
+// per-row capacity (the caller falls back to the host product); the returned matrix is then empty.
+Csr  spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok);
+Csr  transpose(const Csr& a, int ncols, bool* ok);
+// P = P0 - w Dinv (A P0) given AP0 = A P0 (in place on its values): P0 = piecewise constant over agg[]
+void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, double w);
+// finish the SpMV layouts of a matrix whose CSR arrays were just written on the device (spgemm / transpose leave
+// them out: intermediate products never see an SpMV)
+void csr_finish(Csr& a);
+void csr_download(const Csr& a, int* rowptr, int* col, double* val);   // host arrays sized n+1 / nnz / nnz
 // same matrix with every column index c replaced by map_dev[c] (device-side copy: no host round trip)
 Csr  csr_remap_columns(const Csr& a, const int* map_dev);
 void spmv(const Csr& a, const double* x, double* y);                    // y = A x

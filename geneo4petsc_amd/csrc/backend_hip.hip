@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
 }
 
 int spmv_kind();
+static void finish_layout(Csr& a, const int* h_rowptr);
 
 Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
@@ -192,6 +193,13 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
   h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
+  finish_layout(a, h_rowptr);
+  return a;
+}
+// SpMV layouts (LDS row blocks, 64-row slices, long-row list, lanes-per-row choice) of a matrix whose CSR arrays are
+// in HBM; h_rowptr = host copy of the row pointers
+static void finish_layout(Csr& a, const int* h_rowptr) {
+  const int n = a.n;
   int maxrow = 0;
   std::vector<int> longr;
   const int long_len = SELL_LONG;
@@ -252,7 +260,16 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
     a.long_rows = (int*)alloc(sizeof(int) * std::max<size_t>(1, longr.size()));
     h2d(a.long_rows, longr.data(), sizeof(int) * longr.size());
   }
-  return a;
+}
+void csr_finish(Csr& a) {
+  std::vector<int> rp((size_t)a.n + 1);
+  d2h(rp.data(), a.rowptr, sizeof(int) * rp.size());
+  finish_layout(a, rp.data());
+}
+void csr_download(const Csr& a, int* rowptr, int* col, double* val) {
+  d2h(rowptr, a.rowptr, sizeof(int) * ((size_t)a.n + 1));
+  d2h(col, a.col, sizeof(int) * (size_t)a.nnz);
+  d2h(val, a.val, sizeof(double) * (size_t)a.nnz);
 }
 __global__ void k_map_int(int* __restrict__ out, const int* __restrict__ in, const int* __restrict__ map, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -279,6 +296,256 @@ Csr csr_remap_columns(const Csr& a, const int* map_dev) {
   b.long_rows = (int*)dup(a.long_rows, sizeof(int) * std::max<size_t>(1, (size_t)a.nlong));
   return b;
 }
+// =============================================================================== sparse products (multigrid set-up)
+// Row-wise SpGEMM, one wave per output row.  Distinct columns of the row are collected in an LDS hash set
+// (atomicCAS on the keys only), compacted, sorted (bitonic) and written; the values are then accumulated
+// owner-computes: lane t owns the sorted columns t, t+64, ... and scans ALL products of the row in the fixed
+// (k, l) order, so every sum has a fixed order whatever the hash did.  Capacity: SPG_MAXD distinct columns per row.
+constexpr int SPG_HS = 1024;     // hash slots per wave (load factor <= 0.25)
+constexpr int SPG_MAXD = 256;    // distinct columns per output row
+__device__ __forceinline__ void spg_collect(const int* __restrict__ arp, const int* __restrict__ acol,
+                                            const int* __restrict__ brp, const int* __restrict__ bcol, int row,
+                                            int lane, int* keys, int* overflow) {
+  for (int s = lane; s < SPG_HS; s += 64) keys[s] = -1;
+  __builtin_amdgcn_wave_barrier();
+  for (int k = arp[row]; k < arp[row + 1]; ++k) {
+    const int j = acol[k];
+    for (int l = brp[j] + lane; l < brp[j + 1]; l += 64) {
+      const int key = bcol[l];
+      unsigned h = ((unsigned)key * 2654435761u) & (SPG_HS - 1);
+      for (int probe = 0; probe < SPG_HS; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) break;
+        h = (h + 1) & (SPG_HS - 1);
+        if (probe == SPG_HS - 1) *overflow = 1;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(256) void k_spgemm_count(int n, const int* __restrict__ arp, const int* __restrict__ acol,
+                                                      const int* __restrict__ brp, const int* __restrict__ bcol,
+                                                      int* __restrict__ cnt, int* __restrict__ overflow) {
+  __shared__ int keys[4][SPG_HS];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= n) return;
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], overflow);
+  int c = 0;
+  for (int s = lane; s < SPG_HS; s += 64) c += (keys[w][s] != -1) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) {
+    cnt[row] = c;
+    if (c > SPG_MAXD) *overflow = 1;
+  }
+}
+__device__ __forceinline__ void wave_bitonic_sort(int* key, double* val, int N, int lane) {   // N power of two
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < N; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const bool up = ((i & k) == 0);
+          const int a = key[i], b = key[ixj];
+          if ((a > b) == up) {
+            key[i] = b; key[ixj] = a;
+            if (val) { const double t = val[i]; val[i] = val[ixj]; val[ixj] = t; }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restrict__ arp, const int* __restrict__ acol,
+                                                     const double* __restrict__ aval, const int* __restrict__ brp,
+                                                     const int* __restrict__ bcol, const double* __restrict__ bval,
+                                                     const int* __restrict__ crp, int* __restrict__ ccol,
+                                                     double* __restrict__ cval, int* __restrict__ overflow) {
+  __shared__ int keys[4][SPG_HS];
+  __shared__ int list[4][SPG_MAXD];
+  __shared__ int cntl[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= n) return;
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], overflow);
+  const int base = crp[row], cnt = crp[row + 1] - base;
+  if (cnt > SPG_MAXD) return;   // flagged by the count pass
+  if (lane == 0) cntl[w] = 0;
+  for (int t = lane; t < SPG_MAXD; t += 64) list[w][t] = 0x7fffffff;
+  __builtin_amdgcn_wave_barrier();
+  for (int s = lane; s < SPG_HS; s += 64) {
+    const int key = keys[w][s];
+    if (key != -1) list[w][atomicAdd(&cntl[w], 1)] = key;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int N = 64;
+  while (N < cnt) N <<= 1;
+  wave_bitonic_sort(list[w], nullptr, N, lane);
+  int mycol[SPG_MAXD / 64];
+  double acc[SPG_MAXD / 64];
+#pragma unroll
+  for (int u = 0; u < SPG_MAXD / 64; ++u) {
+    const int t = lane + 64 * u;
+    mycol[u] = (t < cnt) ? list[w][t] : -2;
+    acc[u] = 0.0;
+  }
+  const int nu = (cnt + 63) >> 6;
+  for (int k = arp[row]; k < arp[row + 1]; ++k) {
+    const int j = acol[k];
+    const double av = aval[k];
+    for (int l = brp[j]; l < brp[j + 1]; ++l) {      // every lane walks the whole row of B: broadcast loads
+      const int key = bcol[l];
+      const double v = av * bval[l];
+#pragma unroll
+      for (int u = 0; u < SPG_MAXD / 64; ++u)
+        if (u < nu && key == mycol[u]) acc[u] += v;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SPG_MAXD / 64; ++u) {
+    const int t = lane + 64 * u;
+    if (t < cnt) {
+      ccol[base + t] = mycol[u];
+      cval[base + t] = acc[u];
+    }
+  }
+}
+static void host_exclusive_scan(int* dcnt_to_ptr, int n, int64_t* total) {   // rowptr[0..n] from counts in rowptr[1..n]
+  std::vector<int> h((size_t)n + 1, 0);
+  d2h(h.data() + 1, dcnt_to_ptr + 1, sizeof(int) * (size_t)n);
+  int64_t run = 0;
+  for (int i = 1; i <= n; ++i) {
+    run += h[i];
+    h[i] = (int)run;
+  }
+  h[0] = 0;
+  h2d(dcnt_to_ptr, h.data(), sizeof(int) * ((size_t)n + 1));
+  *total = run;
+}
+Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
+  (void)ncols_b;
+  Csr c;
+  *ok = true;
+  c.n = a.n;
+  if (a.n == 0) return c;
+  int* dflag = (int*)alloc(sizeof(int));
+  c.rowptr = (int*)alloc(sizeof(int) * ((size_t)a.n + 1));
+  hipLaunchKernelGGL(k_spgemm_count, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, b.rowptr, b.col,
+                     c.rowptr + 1, dflag);
+  int hflag = 0;
+  d2h(&hflag, dflag, sizeof(int));
+  if (hflag) {
+    dfree(dflag);
+    dfree(c.rowptr);
+    *ok = false;
+    return Csr();
+  }
+  int64_t total = 0;
+  host_exclusive_scan(c.rowptr, a.n, &total);
+  c.nnz = total;
+  c.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)total));
+  c.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)total));
+  hipLaunchKernelGGL(k_spgemm_fill, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
+                     b.col, b.val, c.rowptr, c.col, c.val, dflag);
+  d2h(&hflag, dflag, sizeof(int));
+  dfree(dflag);
+  if (hflag) {
+    dfree(c.rowptr); dfree(c.col); dfree(c.val);
+    *ok = false;
+    return Csr();
+  }
+  return c;
+}
+
+// Transpose: column counts (integer atomics: exact), host scan, scatter with an atomic cursor, then every row of the
+// result is sorted by its column index (= the source row), which restores a unique order.
+constexpr int TR_MAXROW = 1024;
+__global__ void k_col_count(const int* __restrict__ col, int64_t nnz, int* __restrict__ cnt) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&cnt[col[e]], 1);
+}
+__global__ void k_tr_scatter(int n, const int* __restrict__ rp, const int* __restrict__ col, const double* __restrict__ val,
+                             const int* __restrict__ trp, int* __restrict__ cursor, int* __restrict__ tcol,
+                             double* __restrict__ tval) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int k = rp[i]; k < rp[i + 1]; ++k) {
+      const int c = col[k];
+      const int p = trp[c] + atomicAdd(&cursor[c], 1);
+      tcol[p] = i;
+      tval[p] = val[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_sort_rows(int n, const int* __restrict__ rp, int* __restrict__ col,
+                                                   double* __restrict__ val, int* __restrict__ overflow) {
+  __shared__ int key[4][TR_MAXROW];
+  __shared__ double v[4][TR_MAXROW];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= n) return;
+  const int base = rp[row], cnt = rp[row + 1] - base;
+  if (cnt <= 1) return;
+  if (cnt > TR_MAXROW) {
+    if (lane == 0) *overflow = 1;
+    return;
+  }
+  int N = 64;
+  while (N < cnt) N <<= 1;
+  for (int t = lane; t < N; t += 64) {
+    key[w][t] = (t < cnt) ? col[base + t] : 0x7fffffff;
+    v[w][t] = (t < cnt) ? val[base + t] : 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  wave_bitonic_sort(key[w], v[w], N, lane);
+  for (int t = lane; t < cnt; t += 64) {
+    col[base + t] = key[w][t];
+    val[base + t] = v[w][t];
+  }
+}
+Csr transpose(const Csr& a, int ncols, bool* ok) {
+  Csr t;
+  *ok = true;
+  t.n = ncols;
+  t.nnz = a.nnz;
+  t.rowptr = (int*)alloc(sizeof(int) * ((size_t)ncols + 1));
+  t.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)a.nnz));
+  t.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  if (a.nnz > 0)
+    hipLaunchKernelGGL(k_col_count, dim3(gridv(a.nnz)), dim3(256), 0, g_stream, a.col, (int64_t)a.nnz, t.rowptr + 1);
+  int64_t total = 0;
+  host_exclusive_scan(t.rowptr, ncols, &total);
+  int* cursor = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)ncols));
+  int* dflag = (int*)alloc(sizeof(int));
+  if (a.n > 0)
+    hipLaunchKernelGGL(k_tr_scatter, dim3(gridv(a.n)), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, t.rowptr,
+                       cursor, t.col, t.val);
+  if (ncols > 0)
+    hipLaunchKernelGGL(k_sort_rows, dim3((ncols + 3) / 4), dim3(256), 0, g_stream, ncols, t.rowptr, t.col, t.val, dflag);
+  int hflag = 0;
+  d2h(&hflag, dflag, sizeof(int));
+  dfree(dflag);
+  dfree(cursor);
+  if (hflag) {
+    dfree(t.rowptr); dfree(t.col); dfree(t.val);
+    *ok = false;
+    return Csr();
+  }
+  return t;
+}
+__global__ void k_smooth_p(int n, const int* __restrict__ rp, const int* __restrict__ col, double* __restrict__ val,
+                           const int* __restrict__ agg, const double* __restrict__ dinv, double w) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double f = -w * dinv[i];
+    const int mine = agg[i];
+    for (int k = rp[i]; k < rp[i + 1]; ++k) val[k] = f * val[k] + (col[k] == mine ? 1.0 : 0.0);
+  }
+}
+void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, double w) {
+  if (ap0.n == 0) return;
+  hipLaunchKernelGGL(k_smooth_p, dim3(gridv(ap0.n)), dim3(256), 0, g_stream, ap0.n, ap0.rowptr, ap0.col, ap0.val, agg_dev,
+                     dinv_dev, w);
+}
+
 void csr_free(Csr& a) {
   dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
   dfree(a.sl_ptr); dfree(a.sl_col); dfree(a.sl_val); dfree(a.long_rows);

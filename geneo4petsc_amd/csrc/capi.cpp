@@ -558,6 +558,28 @@ PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X, double* Y, 
   return 0;
 }
 
+// test hook for the device sparse products: op 0: C = A B, op 1: C = A^T (B ignored).  Returns nnz(C) (-1: a row
+// exceeded the kernels' capacity, -2: error); fills the outputs when cap >= nnz (rowptr_out has C's rows + 1 entries).
+long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, int ncols, int* rowptr_out, int* col_out,
+                                 double* val_out, long long cap) {
+  try {
+    bk::Csr a = bk::csr_upload(A->n, A->rowptr, A->col, A->val);
+    bk::Csr b;
+    if (op == 0) b = bk::csr_upload(B->n, B->rowptr, B->col, B->val);
+    bool ok = true;
+    bk::Csr c = (op == 0) ? bk::spgemm(a, b, ncols, &ok) : bk::transpose(a, ncols, &ok);
+    long long nnz = ok ? (long long)c.nnz : -1;
+    if (ok && cap >= nnz && rowptr_out) bk::csr_download(c, rowptr_out, col_out, val_out);
+    bk::csr_free(a);
+    if (op == 0) bk::csr_free(b);
+    if (ok) bk::csr_free(c);
+    return nnz;
+  } catch (std::exception& e) {
+    g_global_err = e.what();
+    return -2;
+  }
+}
+
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* TC, int q,
                                 double* out, int reps, double* ms_avg) {
   GUARD_BEGIN

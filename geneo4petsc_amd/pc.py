@@ -279,6 +279,31 @@ class GenEOPC:
             pass
 
 
+def sparse_product(a, b=None, lib=None):
+    """Device sparse products of the multigrid set-up through the test hook: A @ B, or A.T when b is None.
+    Returns a scipy csr_matrix, or None when a row exceeds the kernels' per-row capacity."""
+    import scipy.sparse as sp
+    lib = lib if lib is not None else L.load()
+    aa = _csr_arrays(a)
+    sa = _csr_struct(aa)
+    op, ncols, sb = 1, a.shape[1], None
+    if b is not None:
+        ba = _csr_arrays(b)
+        sb = _csr_struct(ba)
+        op, ncols = 0, b.shape[1]
+    nrows = a.shape[0] if b is not None else a.shape[1]
+    pb = C.byref(sb) if sb is not None else None
+    nnz = lib.GeneoTestSparseProduct(op, C.byref(sa), pb, ncols, None, None, None, 0)
+    if nnz == -1:
+        return None
+    if nnz < 0:
+        raise GenEOError(lib.PCGenEOGetError(None).decode())
+    rp, col, val = np.zeros(nrows + 1, dtype=np.int32), np.zeros(max(1, nnz), dtype=np.int32), np.zeros(max(1, nnz))
+    lib.GeneoTestSparseProduct(op, C.byref(sa), pb, ncols, rp.ctypes.data_as(L.c_int_p), col.ctypes.data_as(L.c_int_p),
+                               val.ctypes.data_as(L.c_dbl_p), nnz)
+    return sp.csr_matrix((val[:nnz], col[:nnz], rp), shape=(nrows, ncols if b is not None else a.shape[0]))
+
+
 class Spmv:
     """Stand-alone CSR SpMV / SpMM handle (the roofline kernel of bench.py)."""
 

@@ -207,6 +207,10 @@ PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, i
  *   epi 1: Y = B - A X      2: Y = Z + A X      3: Y = X + w dinv.*(B - A X)      4: Z = w dinv.*B, Y = B - A Z */
 PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, int m, const double* B_dev,
                               double* Z_dev, const double* dinv_dev, double w);
+/* device sparse products of the multigrid set-up (test hook): op 0: C = A B, op 1: C = A^T; returns nnz(C), -1 when a
+ * row exceeds the kernels' per-row capacity (callers fall back to the host product), -2 on error */
+long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, int ncols, int* rowptr_out, int* col_out,
+                                 double* val_out, long long cap);
 /* per-subdomain tall-skinny kernels on host data (suboff: nsub+1 row offsets):
  *   kind 0: G[s] = S_s^T T_s (p x q)     kind 1: Y_s = S_s C_s (C: nsub x p x q)
  * GeneoSetMFMA(0) selects the plain-FMA twin.  reps > 0 also times it (HIP events). */

@@ -6,6 +6,7 @@
 // tests/hostsim/build.py into tests/hostsim/libgeneopc_hostsim.so.  The product library
 // (geneo4petsc_amd/csrc -> libgeneopc.so) never contains or links this file, and the
 // geneo4petsc_amd package never loads the hostsim library.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,53 @@ Csr csr_remap_columns(const Csr& a, const int* map) {
   Csr b = csr_upload(a.n, a.rowptr, a.col, a.val);
   for (int64_t k = 0; k < a.nnz; ++k) b.col[k] = map[a.col[k]];
   return b;
+}
+static Csr from_rows(int n, const std::vector<std::vector<std::pair<int, double>>>& rows) {
+  std::vector<int> rp(n + 1, 0), col;
+  std::vector<double> val;
+  for (int i = 0; i < n; ++i) {
+    for (auto& e : rows[i]) { col.push_back(e.first); val.push_back(e.second); }
+    rp[i + 1] = (int)col.size();
+  }
+  if (col.empty()) { col.push_back(0); val.push_back(0.0); }
+  return csr_upload(n, rp.data(), col.data(), val.data());
+}
+Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
+  *ok = true;
+  std::vector<std::vector<std::pair<int, double>>> rows(a.n);
+  std::vector<int> pos(ncols_b, -1);
+  for (int i = 0; i < a.n; ++i) {
+    auto& r = rows[i];
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int j = a.col[k];
+      for (int l = b.rowptr[j]; l < b.rowptr[j + 1]; ++l) {
+        const int c = b.col[l];
+        if (pos[c] < 0) { pos[c] = (int)r.size(); r.emplace_back(c, 0.0); }
+        r[pos[c]].second += a.val[k] * b.val[l];
+      }
+    }
+    for (auto& e : r) pos[e.first] = -1;
+    std::sort(r.begin(), r.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+  }
+  return from_rows(a.n, rows);
+}
+Csr transpose(const Csr& a, int ncols, bool* ok) {
+  *ok = true;
+  std::vector<std::vector<std::pair<int, double>>> rows(ncols);
+  for (int i = 0; i < a.n; ++i)
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) rows[a.col[k]].emplace_back(i, a.val[k]);
+  return from_rows(ncols, rows);
+}
+void smooth_prolongator(Csr& ap0, const int* agg, const double* dinv, double w) {
+  for (int i = 0; i < ap0.n; ++i)
+    for (int k = ap0.rowptr[i]; k < ap0.rowptr[i + 1]; ++k)
+      ap0.val[k] = -w * dinv[i] * ap0.val[k] + (ap0.col[k] == agg[i] ? 1.0 : 0.0);
+}
+void csr_finish(Csr&) {}
+void csr_download(const Csr& a, int* rowptr, int* col, double* val) {
+  memcpy(rowptr, a.rowptr, sizeof(int) * (a.n + 1));
+  memcpy(col, a.col, sizeof(int) * a.nnz);
+  memcpy(val, a.val, sizeof(double) * a.nnz);
 }
 void csr_free(Csr& a) { dfree(a.rowptr); dfree(a.col); dfree(a.val); a = Csr(); }
 void spmv(const Csr& a, const double* x, double* y) {
