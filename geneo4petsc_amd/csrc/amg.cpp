@@ -213,6 +213,53 @@ static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
   return rho > 0 ? rho : 2.0;
 }
 
+// dense inverse of every coarsest block (SPD: Cholesky; tiny pivots regularised)
+static void coarse_inverse(const HostCsr& CA, const std::vector<int>& csuboff, std::vector<double>& coarse_inv,
+                           std::vector<int64_t>& coarse_base) {
+  const int nsub = (int)csuboff.size() - 1;
+  struct { const std::vector<int>& suboff; } C{csuboff};
+  coarse_base.assign(nsub + 1, 0);
+  for (int s = 0; s < nsub; ++s) {
+    const int64_t m = C.suboff[s + 1] - C.suboff[s];
+    coarse_base[s + 1] = coarse_base[s] + m * m;
+  }
+  coarse_inv.assign((size_t)std::max<int64_t>(1, coarse_base[nsub]), 0.0);
+  auto invert = [&](int s) {
+    const int r0 = C.suboff[s], m = C.suboff[s + 1] - r0;
+    if (m == 0) return;
+    std::vector<double> a((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i)
+      for (int k = CA.rowptr[r0 + i]; k < CA.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (CA.col[k] - r0)] += CA.val[k];
+    for (int i = 0; i < m; ++i)
+      for (int j = i + 1; j < m; ++j) a[(size_t)i * m + j] = a[(size_t)j * m + i] = 0.5 * (a[(size_t)i * m + j] + a[(size_t)j * m + i]);
+    std::vector<double> l = a;
+    if (!dense::cholesky(l, m)) {
+      double tr = 0.0;
+      for (int i = 0; i < m; ++i) tr += a[(size_t)i * m + i];
+      l = a;
+      for (int i = 0; i < m; ++i) l[(size_t)i * m + i] += 1e-10 * tr / m;
+      if (!dense::cholesky(l, m)) throw std::runtime_error("AMG: coarsest block is not positive definite");
+    }
+    std::vector<double> e(m);
+    double* inv = coarse_inv.data() + coarse_base[s];
+    for (int j = 0; j < m; ++j) {
+      std::fill(e.begin(), e.end(), 0.0);
+      e[j] = 1.0;
+      dense::cholesky_solve(l, m, e.data());
+      for (int i = 0; i < m; ++i) inv[(size_t)i * m + j] = e[i];
+    }
+  };
+  {
+    const int nth = std::max(1, std::min(nsub, std::min(16, (int)std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        for (int s = t; s < nsub; s += nth) invert(s);
+      });
+    for (auto& x : th) x.join();
+  }
+}
+
 void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm,
                     std::vector<AmgLevelHost>& levels, std::vector<double>& coarse_inv,
                     std::vector<int64_t>& coarse_base) {
@@ -311,49 +358,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
     levels.back().A = std::move(Ac);
     levels.back().suboff = csub;
   }
-  // dense inverse of every coarsest block (SPD: Cholesky; tiny pivots regularised)
-  const AmgLevelHost& C = levels.back();
-  const HostCsr& CA = (levels.size() == 1) ? A : C.A;   // a single level: the caller's matrix is the coarsest one
-  coarse_base.assign(nsub + 1, 0);
-  for (int s = 0; s < nsub; ++s) {
-    const int64_t m = C.suboff[s + 1] - C.suboff[s];
-    coarse_base[s + 1] = coarse_base[s] + m * m;
-  }
-  coarse_inv.assign((size_t)std::max<int64_t>(1, coarse_base[nsub]), 0.0);
-  auto invert = [&](int s) {
-    const int r0 = C.suboff[s], m = C.suboff[s + 1] - r0;
-    if (m == 0) return;
-    std::vector<double> a((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i)
-      for (int k = CA.rowptr[r0 + i]; k < CA.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (CA.col[k] - r0)] += CA.val[k];
-    for (int i = 0; i < m; ++i)
-      for (int j = i + 1; j < m; ++j) a[(size_t)i * m + j] = a[(size_t)j * m + i] = 0.5 * (a[(size_t)i * m + j] + a[(size_t)j * m + i]);
-    std::vector<double> l = a;
-    if (!dense::cholesky(l, m)) {
-      double tr = 0.0;
-      for (int i = 0; i < m; ++i) tr += a[(size_t)i * m + i];
-      l = a;
-      for (int i = 0; i < m; ++i) l[(size_t)i * m + i] += 1e-10 * tr / m;
-      if (!dense::cholesky(l, m)) throw std::runtime_error("AMG: coarsest block is not positive definite");
-    }
-    std::vector<double> e(m);
-    double* inv = coarse_inv.data() + coarse_base[s];
-    for (int j = 0; j < m; ++j) {
-      std::fill(e.begin(), e.end(), 0.0);
-      e[j] = 1.0;
-      dense::cholesky_solve(l, m, e.data());
-      for (int i = 0; i < m; ++i) inv[(size_t)i * m + j] = e[i];
-    }
-  };
-  {
-    const int nth = std::max(1, std::min(nsub, std::min(16, (int)std::thread::hardware_concurrency())));
-    std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t)
-      th.emplace_back([&, t]() {
-        for (int s = t; s < nsub; s += nth) invert(s);
-      });
-    for (auto& x : th) x.join();
-  }
+  coarse_inverse((levels.size() == 1) ? A : levels.back().A, levels.back().suboff, coarse_inv, coarse_base);
 }
 
 // ------------------------------------------------------------------------------ device V-cycle
@@ -396,16 +401,9 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
       L.P = bk::csr_upload(H.P.n, H.P.rowptr.data(), H.P.col.data(), H.P.val.data());
       L.R = bk::csr_upload(H.R.n, H.R.rowptr.data(), H.R.col.data(), H.R.val.data());
     }
-    const size_t blk = sizeof(double) * std::max<size_t>(1, (size_t)L.n * maxm);
     L.dinv = (double*)bk::alloc(sizeof(double) * std::max(1, L.n));
     bk::h2d(L.dinv, H.dinv.data(), sizeof(double) * L.n);
-    L.r = (double*)bk::alloc(blk);
-    L.d = (double*)bk::alloc(blk);
-    if (p.smooth_degree > 1) L.ad = (double*)bk::alloc(blk);
-    if (l > 0) {
-      L.b = (double*)bk::alloc(blk);
-      L.x = (double*)bk::alloc(blk);
-    }
+    alloc_level_buffers(L, l > 0);
     L.fused = bk::csr_fusable(L.A) && (l + 1 == (int)levels.size() || bk::csr_fusable(L.P)) && !getenv("GENEO_AMG_UNFUSED");
     if (l == 0) nnz0 = (double)H.nnz;
     nnzt += (double)H.nnz;
@@ -418,6 +416,137 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
   bk::h2d(d_inv, coarse_inv.data(), sizeof(double) * coarse_inv.size());
   d_invbase = (int64_t*)bk::alloc(sizeof(int64_t) * coarse_base.size());
   bk::h2d(d_invbase, coarse_base.data(), sizeof(int64_t) * coarse_base.size());
+}
+
+void AmgDevice::alloc_level_buffers(Lvl& L, bool coarse) {
+  const size_t blk = sizeof(double) * std::max<size_t>(1, (size_t)L.n * maxm);
+  L.r = (double*)bk::alloc(blk);
+  L.d = (double*)bk::alloc(blk);
+  if (prm.smooth_degree > 1) L.ad = (double*)bk::alloc(blk);
+  if (coarse) {
+    L.b = (double*)bk::alloc(blk);
+    L.x = (double*)bk::alloc(blk);
+  }
+}
+
+bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& p, int max_m,
+                                const bk::Csr* fine_dev) {
+  free_all();
+  prm = p;
+  maxm = std::max(1, max_m);
+  const int nsub = (int)suboff.size() - 1;
+  const bool dbg = getenv("GENEO_DEBUG") != nullptr;
+  auto tnow = []() { return std::chrono::high_resolution_clock::now(); };
+  auto tsec = [](std::chrono::high_resolution_clock::time_point a, std::chrono::high_resolution_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+  HostCsr Acur;                       // host copy of the current level's matrix (levels >= 1)
+  std::vector<int> so = suboff;
+  double nnz0 = 0.0, nnzt = 0.0;
+  bk::Csr Adev = *fine_dev;
+  bool own = false;
+  auto abandon = [&]() {
+    if (own) bk::csr_free(Adev);
+    free_all();
+    return false;
+  };
+  for (int l = 0;; ++l) {
+    const HostCsr& Ah = (l == 0) ? A : Acur;
+    auto t_0 = tnow();
+    Lvl L;
+    L.n = Ah.n;
+    L.A = Adev;
+    L.own_A = own;
+    std::vector<double> dinv;
+    L.rho = gershgorin_rho(Ah, dinv);
+    L.dinv = (double*)bk::alloc(sizeof(double) * std::max(1, L.n));
+    bk::h2d(L.dinv, dinv.data(), sizeof(double) * L.n);
+    if (l == 0) nnz0 = (double)Ah.val.size();
+    nnzt += (double)Ah.val.size();
+    int maxblk = 0;
+    for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, so[s + 1] - so[s]);
+    bool last = (maxblk <= prm.coarse_size || l + 1 >= prm.max_levels);
+    std::vector<int> agg, csub(nsub + 1, 0);
+    int nc = 0;
+    if (!last) {  // aggregation per subdomain block, on the host
+      const int n = Ah.n;
+      agg.assign(n, -1);
+      std::vector<int> nagg(nsub, 0);
+      std::vector<std::thread> th;
+      for (int s = 0; s < nsub; ++s)
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], agg); });
+      for (auto& x : th) x.join();
+      for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
+      for (int s = 0; s < nsub; ++s)
+        for (int i = so[s]; i < so[s + 1]; ++i) agg[i] += csub[s];
+      nc = csub[nsub];
+      if (nc >= n) last = true;
+    }
+    auto t_1 = tnow();
+    if (last) {
+      alloc_level_buffers(L, l > 0);
+      L.fused = false;
+      lv.push_back(L);
+      std::vector<double> cinv;
+      std::vector<int64_t> cbase;
+      coarse_inverse(Ah, so, cinv, cbase);
+      cch = bk::chunks_upload(nsub, so.data());
+      d_inv = (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, cinv.size()));
+      bk::h2d(d_inv, cinv.data(), sizeof(double) * cinv.size());
+      d_invbase = (int64_t*)bk::alloc(sizeof(int64_t) * cbase.size());
+      bk::h2d(d_invbase, cbase.data(), sizeof(int64_t) * cbase.size());
+      break;
+    }
+    // ---- device: P0, A P0, P, R = P^T, A P, R A P
+    const int n = Ah.n;
+    bk::Csr P0;
+    {
+      std::vector<int> rp(n + 1);
+      for (int i = 0; i <= n; ++i) rp[i] = i;
+      std::vector<double> ones(n, 1.0);
+      P0 = bk::csr_upload_raw(n, rp.data(), agg.data(), ones.data());
+    }
+    bool ok = true;
+    bk::Csr P = bk::spgemm(Adev, P0, nc, &ok);
+    if (!ok) { bk::csr_free(P0); bk::dfree(L.dinv); return abandon(); }
+    int* d_agg = (int*)bk::alloc(sizeof(int) * n);
+    bk::h2d(d_agg, agg.data(), sizeof(int) * n);
+    bk::smooth_prolongator(P, d_agg, L.dinv, 4.0 / (3.0 * L.rho));
+    bk::dfree(d_agg);
+    bk::csr_free(P0);
+    bk::Csr R = bk::transpose(P, nc, &ok);
+    if (!ok) { bk::csr_free(P); bk::dfree(L.dinv); return abandon(); }
+    bk::Csr AP = bk::spgemm(Adev, P, nc, &ok);
+    if (!ok) { bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
+    bk::Csr Ac = bk::spgemm(R, AP, nc, &ok);
+    bk::csr_free(AP);
+    if (!ok) { bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
+    bk::csr_finish(P);
+    bk::csr_finish(R);
+    bk::csr_finish(Ac);
+    auto t_2 = tnow();
+    L.P = P;
+    L.R = R;
+    alloc_level_buffers(L, l > 0);
+    L.fused = bk::csr_fusable(L.A) && bk::csr_fusable(L.P) && !getenv("GENEO_AMG_UNFUSED");
+    lv.push_back(L);
+    // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse
+    HostCsr next;
+    next.n = nc;
+    next.rowptr.resize((size_t)nc + 1);
+    next.col.resize((size_t)Ac.nnz);
+    next.val.resize((size_t)Ac.nnz);
+    bk::csr_download(Ac, next.rowptr.data(), next.col.data(), next.val.data());
+    if (dbg)
+      fprintf(stderr, "[amg/device] level n %d -> %d nnz %zu -> %zu | host diag+aggregation %.3f, device products %.3f, download %.3f s\n",
+              n, nc, Ah.val.size(), next.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, tnow()));
+    Acur = std::move(next);
+    Adev = Ac;
+    own = true;
+    so = csub;
+  }
+  opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;
+  return true;
 }
 
 void AmgDevice::applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m) {

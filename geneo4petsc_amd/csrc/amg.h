@@ -42,6 +42,13 @@ class AmgDevice {
   // fine_dev: the level-0 matrix if it already lives in HBM (borrowed, not freed), else nullptr
   void upload(const std::vector<AmgLevelHost>& levels, const std::vector<double>& coarse_inv,
               const std::vector<int64_t>& coarse_base, const AmgParams& prm, int max_m, const bk::Csr* fine_dev);
+  // The same hierarchy with the Galerkin products on the device: per level the host only aggregates (it needs the
+  // level's matrix: the caller's at level 0, a download of the coarse one further down) and computes the Jacobi
+  // diagonal; P = (I - w D^-1 A) P0, R = P^T, A P and R A P are device sparse products (backend.h) and never leave
+  // HBM.  Returns false (nothing built) when a row exceeds the product kernels' capacity: the caller then takes
+  // amg_setup_host + upload.
+  bool build_on_device(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm, int max_m,
+                       const bk::Csr* fine_dev);
   // X = V(B) with zero initial guess; B, X: n0 x m row-major with leading dimensions ldb / ldx
   void vcycle(const double* B, int ldb, double* X, int ldx, int m);
   int nlevels() const { return (int)lv.size(); }
@@ -65,6 +72,7 @@ class AmgDevice {
   AmgParams prm;
   int maxm = 1;
   double opc = 1.0;
+  void alloc_level_buffers(Lvl& L, bool coarse);
   void applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m);
   void smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int m, bool zero_guess);
   void cycle(int l, const double* B, int ldb, double* X, int ldx, int m);

@@ -52,6 +52,7 @@ struct Csr {
                                // lanes-per-row CSR kernel with this many lanes per row instead of the slices
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
+Csr  csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h_val);   // CSR arrays only (no SpMV layouts)
 void csr_free(Csr& a);
 // ---- sparse products on the device (multigrid set-up: Galerkin products without a host round trip) ----------------
 // C = A B (B has ncols_b columns) and A^T (A has ncols columns).  Columns come out sorted inside every row and

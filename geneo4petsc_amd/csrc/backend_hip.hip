@@ -183,6 +183,18 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
 int spmv_kind();
 static void finish_layout(Csr& a, const int* h_rowptr);
 
+Csr csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
+  Csr a;
+  a.n = n;
+  a.nnz = h_rowptr[n];
+  a.rowptr = (int*)alloc(sizeof(int) * (size_t)(n + 1));
+  a.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)a.nnz));
+  a.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
+  h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
+  h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
+  return a;
+}
 Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
   a.n = n;

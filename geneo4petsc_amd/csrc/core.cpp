@@ -521,29 +521,9 @@ int PC::setup(const double* b_dev) {
   }
   auto t1 = clk::now();
   HostCsr h_neuL = make_blockdiag(neu, suboff, nullptr);
-  // The eigensolve waits for the A_Neu hierarchy: its host set-up starts NOW on its own thread and the
-  // uploads / sliced-layout builds / diagonals below overlap it.
   const bool want1 = (opt.dls1_pc == "amg");
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
   const AmgParams ap = amg_params(opt);
-  AmgHostResult rN;
-  std::thread thN;
-  struct Joiner {
-    std::thread& t;
-    ~Joiner() {
-      if (t.joinable()) t.join();
-    }
-  } joinN{thN};
-  if (wantN)
-    thN = std::thread([&h_neuL, &rN, ap, this]() {
-      auto t0 = clk::now();
-      try {
-        amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
-      } catch (std::exception& e) {
-        rN.err = e.what();
-      }
-      rN.secs = secs(t0, clk::now());
-    });
   neuL = upload_host(h_neuL);
   // same matrix with ext-space columns (l2e o col) for the MATIS MatMult, so that the gather R x is fused into the
   // SpMV; own copy (the sliced layout embeds the columns), made on the device from the one just uploaded
@@ -606,7 +586,6 @@ int PC::setup(const double* b_dev) {
     auto ta = clk::now();
     pend1.reset(want1 ? new Amg1Pending() : nullptr);
     if (want1) pend1->mat = std::move(h_dirL);
-    const bool overlap1 = want1 && wantN && !getenv("GENEO_AMG_NO_OVERLAP");
     auto start1 = [this, ap]() {
       Amg1Pending* pp = pend1.get();
       const std::vector<int> so = suboff;
@@ -620,26 +599,30 @@ int PC::setup(const double* b_dev) {
         pp->res.secs = secs(t0, clk::now());
       });
     };
-    if (want1 && !overlap1) start1();
-    if (thN.joinable()) thN.join();
-    if (overlap1) start1();
-    if (!rN.err.empty()) return fail(rN.err);
-    try {
-      if (wantN) {
-        const int max_m = eig_block_max();
+    // The level-1 (A_Dir / A_Rob) hierarchy is not needed before the solve: host set-up on its own thread, joined
+    // after the eigensolve.  The A_Neu hierarchy (LOBPCG waits for it) is built with the sparse products on the
+    // device; the host only aggregates.  Fallback to the host products when a row exceeds the kernels' capacity.
+    if (want1) start1();
+    if (wantN) {
+      try {
         amgN = new AmgDevice();
-        amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, max_m, &neuL);
+        bool built = false;
+        if (!getenv("GENEO_AMG_HOST")) built = amgN->build_on_device(h_neuL, suboff, ap, eig_block_max(), &neuL);
+        if (!built) {
+          AmgHostResult rN;
+          amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
+          amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, eig_block_max(), &neuL);
+        }
         info.amg_levels = amgN->nlevels();
         info.amg_operator_complexity = amgN->operator_complexity();
+        info.amg_on_device = built ? 1 : 0;
+      } catch (std::exception& e) {
+        return fail(e.what());
       }
-    } catch (std::exception& e) {
-      return fail(e.what());
     }
     bk::sync();
     info.amgSetupTime = secs(ta, clk::now());
-    if (getenv("GENEO_DEBUG"))
-      fprintf(stderr, "[amg] A_Neu host set-up %.3f s (started %.3f s before this point), waited + upload %.3f s\n", rN.secs,
-              secs(t1, ta), info.amgSetupTime);
+    if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] A_Neu hierarchy (%s products) %.3f s\n", info.amg_on_device ? "device" : "host", info.amgSetupTime);
     if (want1 && !opt.lvl2)
       if (int rc = finish_amg1()) return rc;
   }

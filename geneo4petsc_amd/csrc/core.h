@@ -66,7 +66,7 @@ struct Info {                 // public counters / timers of geneoContext (hdr/g
          lvl2ApplyZTimeLoc = 0;
   double setupTime = 0, solveTime = 0;
   long long spmv_calls = 0;
-  int amg_levels = 0;
+  int amg_levels = 0, amg_on_device = 0;
   double amg_operator_complexity = 0.0, amgSetupTime = 0.0;
 };
 

@@ -90,6 +90,7 @@ void smooth_prolongator(Csr& ap0, const int* agg, const double* dinv, double w) 
       ap0.val[k] = -w * dinv[i] * ap0.val[k] + (ap0.col[k] == agg[i] ? 1.0 : 0.0);
 }
 void csr_finish(Csr&) {}
+Csr csr_upload_raw(int n, const int* rp, const int* col, const double* val) { return csr_upload(n, rp, col, val); }
 void csr_download(const Csr& a, int* rowptr, int* col, double* val) {
   memcpy(rowptr, a.rowptr, sizeof(int) * (a.n + 1));
   memcpy(col, a.col, sizeof(int) * a.nnz);
