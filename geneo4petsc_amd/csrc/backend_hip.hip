@@ -17,6 +17,7 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -34,6 +35,7 @@
 namespace bk {
 
 static hipStream_t g_stream = nullptr;
+static bool g_capturing = false;   // between graph_capture_begin and graph_capture_end
 static bool g_no_mfma = false;
 static bool g_init = false;
 
@@ -60,13 +62,62 @@ void* alloc(size_t bytes) {
 void dfree(void* p) {
   if (p) (void)hipFree(p);
 }
+// Large transfers from / to pageable host memory (CSR arrays of the fine matrices, downloaded coarse operators)
+// go through two pinned staging buffers: the host memcpy of one chunk overlaps the DMA of the other.  Small
+// transfers take the plain path (their cost is the synchronisation, not the bandwidth).
+constexpr size_t STAGE_BYTES = (size_t)16 << 20;
+static char* g_stage[2] = {nullptr, nullptr};
+static hipEvent_t g_stage_ev[2];
+static bool stage_ready() {
+  if (g_stage[0]) return true;
+  if (getenv("GENEO_NO_PINNED_STAGING")) return false;
+  for (int i = 0; i < 2; ++i) {
+    if (hipHostMalloc((void**)&g_stage[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      if (i == 1) (void)hipHostFree(g_stage[0]);
+      g_stage[0] = g_stage[1] = nullptr;
+      return false;
+    }
+    HIPCHK(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+  }
+  return true;
+}
 void h2d(void* d, const void* h, size_t bytes) {
   if (!bytes) return;
+  if (bytes >= 2 * STAGE_BYTES && !g_capturing && stage_ready()) {
+    size_t off = 0;
+    for (int i = 0; off < bytes; ++i, off += STAGE_BYTES) {
+      const int b = i & 1;
+      const size_t len = std::min(STAGE_BYTES, bytes - off);
+      if (i >= 2) HIPCHK(hipEventSynchronize(g_stage_ev[b]));      // the DMA that last used this buffer is done
+      std::memcpy(g_stage[b], (const char*)h + off, len);
+      HIPCHK(hipMemcpyAsync((char*)d + off, g_stage[b], len, hipMemcpyHostToDevice, g_stream));
+      HIPCHK(hipEventRecord(g_stage_ev[b], g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return;
+  }
   HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));  // h may be pageable / reused by the caller
 }
 void d2h(void* h, const void* d, size_t bytes) {
   if (!bytes) return;
+  if (bytes >= 2 * STAGE_BYTES && !g_capturing && stage_ready()) {
+    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    auto issue = [&](size_t i) {
+      const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
+      HIPCHK(hipMemcpyAsync(g_stage[i & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, g_stream));
+      HIPCHK(hipEventRecord(g_stage_ev[i & 1], g_stream));
+    };
+    issue(0);
+    for (size_t i = 0; i < nchunk; ++i) {
+      if (i + 1 < nchunk) issue(i + 1);                             // next chunk's DMA runs during this memcpy
+      HIPCHK(hipEventSynchronize(g_stage_ev[i & 1]));
+      const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
+      std::memcpy((char*)h + off, g_stage[i & 1], len);
+    }
+    return;
+  }
   HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
 }
@@ -81,7 +132,6 @@ void zero(void* d, size_t bytes) {
 
 // ---- HIP graphs: capture on a private stream, replay on the launch stream ----------------------------
 static hipStream_t g_capture_stream = nullptr, g_saved_stream = nullptr;
-static bool g_capturing = false;
 bool graph_capture_begin() {
   if (g_capturing || getenv("GENEO_NO_GRAPH")) return false;
   if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {

@@ -524,12 +524,24 @@ int PC::setup(const double* b_dev) {
   const bool want1 = (opt.dls1_pc == "amg");
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
   const AmgParams ap = amg_params(opt);
+  auto tdbg = clk::now();
+  auto lap = [&](const char* what) {
+    if (!getenv("GENEO_DEBUG")) return;
+    bk::sync();
+    fprintf(stderr, "[setup] %-28s %.3f s\n", what, secs(tdbg, clk::now()));
+    tdbg = clk::now();
+  };
+  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] %-28s %.3f s\n", "layout + Dirichlet + A_Neu blockdiag", secs(t0, tdbg));
   neuL = upload_host(h_neuL);
+  lap("upload A_Neu");
   // same matrix with ext-space columns (l2e o col) for the MATIS MatMult, so that the gather R x is fused into the
   // SpMV; own copy (the sliced layout embeds the columns), made on the device from the one just uploaded
   neuE = bk::csr_remap_columns(neuL, d_l2e);
+  lap("ext-space copy");
   HostCsr h_dirL = make_blockdiag(lvl1, suboff, nullptr);
+  lap("A_Dir blockdiag");
   dirL = upload_host(h_dirL);
+  lap("upload A_Dir");
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {
     std::vector<double> D(std::max(1, nL));
@@ -583,6 +595,7 @@ int PC::setup(const double* b_dev) {
     // Inner AMG hierarchies: A_Neu (LOBPCG preconditioner) first -- the eigensolve is waiting for it --
     // then A_Dir / A_Rob (local solves), whose host set-up runs on its own thread WHILE the GPU is busy
     // with the eigensolve; it is joined and uploaded when level 2 is done (or right away without level 2).
+    lap("diagonals");
     auto ta = clk::now();
     pend1.reset(want1 ? new Amg1Pending() : nullptr);
     if (want1) pend1->mat = std::move(h_dirL);
