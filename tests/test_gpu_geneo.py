@@ -138,3 +138,34 @@ def test_dummy_goldens_on_gpu(lib, rec):
     x, its, rnorm, reason = pc.solve(b)
     assert reason.startswith("KSP_CONVERGED")
     np.testing.assert_allclose(x, rec["x"], rtol=1e-5, atol=1e-6)
+
+
+def test_hub_row_falls_back_to_host_products(lib, capfd, monkeypatch):
+    """A hub node tied to 300 scattered grid nodes: its row of A P has more than 256 distinct columns, the device
+    sparse product reports the overflow, the partly built hierarchy is dropped and the host products take over --
+    same answer as the oracle."""
+    from geneo4petsc_amd import decomp
+    nx = 40
+    idx = lambda i, j: i + nx * j
+    ptr, elems, mats = [0], [], []
+    e2 = [1.0001, -1.0, -1.0, 1.0001]
+    for j in range(nx):
+        for i in range(nx):
+            if i + 1 < nx:
+                elems += [idx(i, j), idx(i + 1, j)]; ptr.append(len(elems)); mats.append(e2)
+            if j + 1 < nx:
+                elems += [idx(i, j), idx(i, j + 1)]; ptr.append(len(elems)); mats.append(e2)
+    hub = nx * nx
+    rng = np.random.default_rng(5)
+    for t in rng.choice(nx * nx, size=300, replace=False):
+        elems += [int(t), hub]; ptr.append(len(elems)); mats.append([0.0101, -0.01, -0.01, 0.0101])
+    mesh = decomp.mesh_from_lists(hub + 1, ptr, elems, mats)
+    npart = (np.arange(hub + 1) >= (hub + 1) // 2).astype(np.int64)
+    dec = decomp.decompose(mesh, 2, None, npart, False, 1)
+    a = decomp.global_matrix(mesh)
+    b = decomp.rhs_default(a)
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.05", "-geneo_cut", "6", "-ksp_type", "cg", "-amg_coarse_size", "200"] + TIGHT
+    monkeypatch.setenv("GENEO_DEBUG", "1")
+    cases.compare_with_oracle(lib, 0, None, 1, argv, case=(mesh, dec, a, b), aptol=1e-8)
+    err = capfd.readouterr().err
+    assert "A_Neu hierarchy (host products)" in err
