@@ -835,7 +835,7 @@ void PC::coarse_solve_local(const double* xL, double* yE) {
   allreduce(yE, dimE);
   bk::d2h(h_yE.data(), yE, sizeof(double) * dimE);
   auto t1 = clk::now();
-  if (E_chol) dense::cholesky_solve(Efac, dimE, h_yE.data());
+  if (E_chol) dense::cholesky_solve_lu(Efac, EfacT, dimE, h_yE.data());
   else dense::lu_solve(Efac, dimE, Epiv, h_yE.data());
   bk::h2d(yE, h_yE.data(), sizeof(double) * dimE);
   auto t2 = clk::now();
@@ -1930,7 +1930,12 @@ int PC::build_E() {
     for (int b = a + 1; b < dimE; ++b) Efac[(size_t)a * dimE + b] = Efac[(size_t)b * dimE + a] =
         0.5 * (Efac[(size_t)a * dimE + b] + Efac[(size_t)b * dimE + a]);
   std::vector<double> sym = Efac;
-  E_chol = dense::cholesky(Efac, dimE);
+  E_chol = dense::cholesky_blocked(Efac, dimE, (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+  if (E_chol) {   // U = L^T next to L: the backward substitution then walks contiguous rows too
+    EfacT.assign(Efac.size(), 0.0);
+    for (int a = 0; a < dimE; ++a)
+      for (int b = 0; b <= a; ++b) EfacT[(size_t)b * dimE + a] = Efac[(size_t)a * dimE + b];
+  }
   if (!E_chol) {
     Efac = sym;
     if (!dense::lu_factor(Efac, dimE, Epiv)) return fail("GenEO - solve KO: dcs2 (singular coarse operator E)");

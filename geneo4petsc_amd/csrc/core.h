@@ -148,7 +148,7 @@ class PC {
   std::vector<int> ksub, zoff;
   int kmax = 0, dimE = 0;
   double* d_yE = nullptr;
-  std::vector<double> Efac;
+  std::vector<double> Efac, EfacT;
   std::vector<int> Epiv;
   bool E_chol = true;
   std::vector<double> h_yE;

@@ -5,6 +5,8 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <thread>
 #include <vector>
 
 namespace dense {
@@ -36,6 +38,91 @@ inline void cholesky_solve(const std::vector<double>& l, int n, double* x) {
     double s = x[i];
     for (int k = i + 1; k < n; ++k) s -= l[k * n + i] * x[k];
     x[i] = s / l[i * n + i];
+  }
+}
+
+// Blocked right-looking Cholesky for the replicated coarse operator E when it gets large (dimE = 20 per subdomain:
+// 1280 on 8 GPUs): the panel solve and the trailing update run over row ranges on host threads, every inner loop is
+// a contiguous dot product of two 64-long row pieces.  Same result layout as cholesky() (lower, in place).
+inline bool cholesky_blocked(std::vector<double>& a, int n, int nthreads) {
+  constexpr int NB = 64;
+  if (n < 4 * NB || nthreads <= 1) return cholesky(a, n);
+  auto par = [&](int lo, int hi, const std::function<void(int)>& f) {   // rows lo..hi-1 dealt round-robin (triangular work)
+    const int nt = std::max(1, std::min(nthreads, hi - lo));
+    if (nt == 1) {
+      for (int i = lo; i < hi; ++i) f(i);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&, t]() {
+        for (int i = lo + t; i < hi; i += nt) f(i);
+      });
+    for (auto& x : th) x.join();
+  };
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int kb = std::min(NB, n - k0), k1 = k0 + kb;
+    for (int j = k0; j < k1; ++j) {                      // diagonal block, unblocked
+      double d = a[(size_t)j * n + j];
+      for (int k = k0; k < j; ++k) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+      if (!(d > 0.0)) return false;
+      d = std::sqrt(d);
+      a[(size_t)j * n + j] = d;
+      for (int i = j + 1; i < k1; ++i) {
+        double s2 = a[(size_t)i * n + j];
+        for (int k = k0; k < j; ++k) s2 -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+        a[(size_t)i * n + j] = s2 / d;
+      }
+    }
+    if (k1 >= n) break;
+    par(k1, n, [&](int i) {                               // panel: L[i, k0:k1] = A[i, k0:k1] L_kk^-T
+      double* ri = a.data() + (size_t)i * n;
+      for (int c = k0; c < k1; ++c) {
+        const double* rc = a.data() + (size_t)c * n;
+        double s2 = ri[c];
+        for (int t = k0; t < c; ++t) s2 -= ri[t] * rc[t];
+        ri[c] = s2 / rc[c];
+      }
+    });
+    par(k1, n, [&](int i) {                               // trailing update, lower triangle: A[i, j] -= L[i,blk] . L[j,blk]
+      double* ri = a.data() + (size_t)i * n;
+      int j = k1;
+      for (; j + 3 <= i; j += 4) {                        // four rows of L per pass: the 64-long piece of row i is reused
+        const double* r0 = a.data() + (size_t)j * n;
+        const double *r1 = r0 + n, *r2 = r1 + n, *r3 = r2 + n;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int t = k0; t < k1; ++t) {
+          const double v = ri[t];
+          s0 += v * r0[t];
+          s1 += v * r1[t];
+          s2 += v * r2[t];
+          s3 += v * r3[t];
+        }
+        ri[j] -= s0; ri[j + 1] -= s1; ri[j + 2] -= s2; ri[j + 3] -= s3;
+      }
+      for (; j <= i; ++j) {
+        const double* rj = a.data() + (size_t)j * n;
+        double s2 = 0.0;
+        for (int t = k0; t < k1; ++t) s2 += ri[t] * rj[t];
+        ri[j] -= s2;
+      }
+    });
+  }
+  return true;
+}
+// solve L L^T x = b with U = L^T stored row-major next to L: both substitutions walk contiguous rows
+inline void cholesky_solve_lu(const std::vector<double>& l, const std::vector<double>& u, int n, double* x) {
+  for (int i = 0; i < n; ++i) {
+    const double* li = l.data() + (size_t)i * n;
+    double s = x[i];
+    for (int k = 0; k < i; ++k) s -= li[k] * x[k];
+    x[i] = s / li[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const double* ui = u.data() + (size_t)i * n;
+    double s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= ui[k] * x[k];
+    x[i] = s / ui[i];
   }
 }
 
