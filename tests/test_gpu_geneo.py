@@ -169,3 +169,10 @@ def test_hub_row_falls_back_to_host_products(lib, capfd, monkeypatch):
     cases.compare_with_oracle(lib, 0, None, 1, argv, case=(mesh, dec, a, b), aptol=1e-8)
     err = capfd.readouterr().err
     assert "A_Neu hierarchy (host products)" in err
+
+
+def test_large_coarse_operator_blocked_cholesky(lib):
+    """dimE = 312 and a 64-column LOBPCG block (192-column Gram / block update kernels); E through the blocked Cholesky."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "39", "-ksp_type", "cg"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv)
+    assert info["dimE"] == 312

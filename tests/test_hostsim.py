@@ -221,3 +221,11 @@ def test_E_blocked_and_columnwise_assembly_agree(lib, monkeypatch):
     assert e_blocked.shape == e_col.shape == orc.E.shape
     np.testing.assert_allclose(e_blocked, e_col, rtol=1e-11, atol=1e-12 * np.abs(e_col).max())
     np.testing.assert_allclose(np.linalg.eigvalsh(0.5 * (e_blocked + e_blocked.T)), np.linalg.eigvalsh(orc.E), rtol=1e-8)
+
+
+def test_large_coarse_operator_blocked_cholesky(lib):
+    """dimE = 312 (39 vectors x 8 subdomains, 64-column LOBPCG block): E goes through the blocked, threaded Cholesky
+    and the transposed-factor back substitution instead of the small-matrix routine."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "39", "-ksp_type", "cg"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv)
+    assert info["dimE"] == 312
