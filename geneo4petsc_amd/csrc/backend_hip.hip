@@ -17,6 +17,7 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <chrono>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -51,16 +52,28 @@ void set_stream(void* s) { g_stream = (hipStream_t)s; }
 void* get_stream() { return (void*)g_stream; }
 void sync() { HIPCHK(hipStreamSynchronize(g_stream)); }
 
+static double g_alloc_s = 0.0, g_free_s = 0.0;
+static long long g_alloc_n = 0;
 void* alloc(size_t bytes) {
   lazy_init();
   void* p = nullptr;
   if (bytes == 0) bytes = 8;
+  auto t0 = std::chrono::high_resolution_clock::now();
   HIPCHK(hipMalloc(&p, bytes));
+  g_alloc_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  ++g_alloc_n;
   HIPCHK(hipMemsetAsync(p, 0, bytes, g_stream));
   return p;
 }
 void dfree(void* p) {
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  auto t0 = std::chrono::high_resolution_clock::now();
+  (void)hipFree(p);
+  g_free_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+}
+void alloc_stats(double* alloc_s, double* free_s, long long* n) {
+  *alloc_s = g_alloc_s; *free_s = g_free_s; *n = g_alloc_n;
+  g_alloc_s = g_free_s = 0.0; g_alloc_n = 0;
 }
 // Large transfers from / to pageable host memory (CSR arrays of the fine matrices, downloaded coarse operators)
 // go through two pinned staging buffers: the host memcpy of one chunk overlaps the DMA of the other.  Small

@@ -662,6 +662,12 @@ int PC::setup(const double* b_dev) {
   }
   bk::sync();
   info.setupTime = secs(t0, clk::now());
+  if (getenv("GENEO_DEBUG")) {
+    double as = 0, fs = 0;
+    long long na = 0;
+    bk::alloc_stats(&as, &fs, &na);
+    fprintf(stderr, "[setup] total %.3f s; since the previous report: %lld hipMalloc %.3f s, hipFree %.3f s\n", info.setupTime, na, as, fs);
+  }
   return 0;
 }
 

@@ -25,6 +25,7 @@ void sync() {}
 
 void* alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { free(p); }
+void alloc_stats(double* a, double* f, long long* n) { *a = 0; *f = 0; *n = 0; }
 void h2d(void* d, const void* h, size_t b) { if (b) memcpy(d, h, b); }
 void d2h(void* h, const void* d, size_t b) { if (b) memcpy(h, d, b); }
 void d2d(void* d, const void* s, size_t b) { if (b) memmove(d, s, b); }
