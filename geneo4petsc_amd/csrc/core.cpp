@@ -237,6 +237,10 @@ int PC::add_subdomain(int gid, int n, const int* l2g, const int* mult, const int
 
 int PC::set_intersect(int gid, int nb, const int* nonempty) {
   if (nb < 0 || (nb > 0 && !nonempty)) return fail("GenEO preconditioner: bad intersection flags");
+  if (gid < 0 && !subs.empty()) {   // the subdomain added last (initGenEOPC: the caller does not know the id)
+    subs.back().intersect.assign(nonempty, nonempty + nb);
+    return 0;
+  }
   for (auto& s : subs)
     if (s.gid == gid) {
       s.intersect.assign(nonempty, nonempty + nb);

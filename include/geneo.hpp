@@ -36,10 +36,13 @@ inline PetscErrorCode initGenEOPC(PC& pcPC, unsigned int const& nbDOF, unsigned 
                                   std::vector<unsigned int> const* const dofIdxMultLoc,
                                   std::vector<std::vector<unsigned int>> const* const intersectLoc) {
   (void)dofIdxDomLoc;
-  (void)intersectLoc;
   if (!dofIdxMultLoc || dofIdxMultLoc->size() != nbDOFLoc || pcMap.size() != nbDOFLoc) return 1;
-  return initGenEOPC_c(pcPC, nbDOF, nbDOFLoc, pcMap.data(), &pcA, pcADirLoc, pcB_dev, pcX0_dev,
-                       dofIdxMultLoc->data());
+  PetscErrorCode rc = initGenEOPC_c(pcPC, nbDOF, nbDOFLoc, pcMap.data(), &pcA, pcADirLoc, pcB_dev, pcX0_dev,
+                                    dofIdxMultLoc->data());
+  if (rc || !intersectLoc) return rc;
+  std::vector<int> nonempty(intersectLoc->size());     // GenEO-2 reads only the emptiness of each list (geneo.cpp:1139-1148)
+  for (size_t q = 0; q < intersectLoc->size(); ++q) nonempty[q] = (*intersectLoc)[q].empty() ? 0 : 1;
+  return PCGenEOSetIntersect(pcPC, -1, (int)nonempty.size(), nonempty.data());   // -1: the subdomain just added
 }
 
 /* usageGenEO: usage of GenEO (printf stands for PetscPrintf). */

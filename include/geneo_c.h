@@ -101,7 +101,7 @@ PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int nbDOFLoc, const int* map,
 
 /* intersectLoc of initGenEOPC (hdr/geneo.hpp:34): nonempty[q] != 0 iff subdomain gid shares DOFs with
  * subdomain q.  Only GenEO-2's gamma_loc reads it (src/geneo.cpp:1139-1148); on one rank it is derived
- * from the maps when absent. */
+ * from the maps when absent.  gid < 0 addresses the subdomain added last. */
 PetscErrorCode PCGenEOSetIntersect(PC pc, int gid, int nbSubdomainsGlobal, const int* nonempty);
 
 /* ---- multi-rank plumbing (one process per GPU; the transport is supplied by the host) ----- */

@@ -5,6 +5,7 @@ import re
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,3 +57,56 @@ def test_no_cpu_fallback_in_package():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "libgeneopc_hostsim" not in txt, f
+
+
+def test_cpp_mirror_header_compiles_and_runs(tmp_path):
+    """include/geneo.hpp (initGenEOPC / usageGenEO / geneoContext with the reference's argument order) compiled by g++
+    against the C ABI and run on the test-only host backend: one subdomain, tridiag(-1, 2.0001, -1)."""
+    import subprocess
+    import hostsim_util as hu
+    so = hu.hostsim_path() if hasattr(hu, "hostsim_path") else None
+    hu.hostsim_lib()
+    so = so or os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libgeneopc_hostsim.so")
+    src = tmp_path / "mirror.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include <vector>
+#include "geneo.hpp"
+int main() {
+  const int n = 8;
+  std::vector<int> rp(n + 1, 0), col; std::vector<double> val;
+  for (int i = 0; i < n; ++i) {
+    if (i > 0) { col.push_back(i - 1); val.push_back(-1.0); }
+    col.push_back(i); val.push_back(2.0001);
+    if (i + 1 < n) { col.push_back(i + 1); val.push_back(-1.0); }
+    rp[i + 1] = (int)col.size();
+  }
+  GeneoCsr A{n, rp.data(), col.data(), val.data()};
+  std::vector<int> map(n); for (int i = 0; i < n; ++i) map[i] = i;
+  std::vector<unsigned int> dofs(n), mult(n, 1u); for (int i = 0; i < n; ++i) dofs[i] = i;
+  std::vector<std::vector<unsigned int>> inter(1);
+  PC pc;
+  if (PCCreate_GenEO(&pc)) return 1;
+  const char* argv[] = {"-geneo_lvl", "ASM,1", "-geneo_tau", "0.5"};
+  if (PCSetFromOptions_GenEO(pc, 4, argv)) return 2;
+  std::vector<double> b(n, 1.0), x0(n, 0.0), y(n, 0.0);
+  if (initGenEOPC(pc, n, n, map, A, nullptr, b.data(), x0.data(), &dofs, &mult, &inter)) return 3;
+  if (PCSetUp_GenEO(pc)) { std::printf("setup: %s\n", PCGenEOGetError(pc)); return 4; }
+  if (PCApply_GenEO(pc, b.data(), y.data())) return 5;
+  geneoContext ctx;
+  if (ctx.refresh(pc)) return 6;
+  std::string u = usageGenEO(false);
+  std::printf("%s %d %d %.6f\n", ctx.name.c_str(), ctx.realDimELoc, (int)(u.find("-geneo_lvl") != std::string::npos), y[0]);
+  return PCDestroy_GenEO(&pc);
+}
+""")
+    exe = tmp_path / "mirror"
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["g++", "-std=c++17", "-I", inc, str(src), so, "-Wl,-rpath," + os.path.dirname(so), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    name, dim, has_usage, y0 = out.stdout.split()
+    assert name == "geneo1ASM" and int(dim) >= 1 and has_usage == "1"
+    # one subdomain covering everything: y = (A^-1 + Z E^-1 Z^T) b, both terms positive for b = 1 on this M-matrix
+    a = np.diag(np.full(8, 2.0001)) + np.diag(np.full(7, -1.0), 1) + np.diag(np.full(7, -1.0), -1)
+    assert float(y0) >= np.linalg.solve(a, np.ones(8))[0] * (1 - 1e-9)
