@@ -29,6 +29,7 @@
 #ifndef __GENEO_C_H
 #define __GENEO_C_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -110,3 +110,13 @@ int main() {
     # one subdomain covering everything: y = (A^-1 + Z E^-1 Z^T) b, both terms positive for b = 1 on this M-matrix
     a = np.diag(np.full(8, 2.0001)) + np.diag(np.full(7, -1.0), 1) + np.diag(np.full(7, -1.0), -1)
     assert float(y0) >= np.linalg.solve(a, np.ones(8))[0] * (1 - 1e-9)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/geneo_c.h must compile as C99 with -pedantic (no C++, no torch types)."""
+    import subprocess
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "geneo_c.h"\nint main(void) { PC pc; GeneoInput in; GeneoInfo info; (void)in; (void)info;\n'
+                   '  return PCCreate_GenEO(&pc) ? 1 : PCDestroy_GenEO(&pc); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "cabi.o")])
