@@ -140,6 +140,28 @@ class GenEOPC:
                                                mult.ctypes.data_as(L.c_int_p), C.byref(sn),
                                                C.byref(sd) if sd is not None else None))
 
+    def setup_from_operators(self, nbDOF, pcMap, a_local, dofMultiplicities, pcADirLoc=None, dofIntersections=None):
+        """The reference's PETSc-style pair (hdr/geneo_c.h:10): KSPSetOperators(MATIS A) then
+        PCGenEOSetup(pc, pcADirLoc, dofMultiplicities, dofIntersections) -- one subdomain for this rank."""
+        l2g = np.ascontiguousarray(pcMap, dtype=np.int32)
+        mult = np.ascontiguousarray(dofMultiplicities, dtype=np.int32)
+        an = _csr_arrays(a_local)
+        mat = L.GeneoMatIS(int(nbDOF), len(l2g), l2g.ctypes.data_as(L.c_int_p), _csr_struct(an))
+        self.N = int(nbDOF)
+        if self.n_owned is None:
+            self.n_owned = int(nbDOF)
+        self._chk(self.lib.PCSetOperators_GenEO(self.h, C.byref(mat)))
+        sd = None
+        if pcADirLoc is not None:
+            ad = _csr_arrays(pcADirLoc)
+            sd = _csr_struct(ad)
+        inter = None
+        if dofIntersections is not None:
+            keep = [np.ascontiguousarray(x, dtype=np.int32) for x in dofIntersections]
+            inter = (L.GeneoIS * len(keep))(*[L.GeneoIS(len(x), x.ctypes.data_as(L.c_int_p)) for x in keep])
+        self._chk(self.lib.PCGenEOSetup(self.h, C.byref(sd) if sd is not None else None,
+                                        L.GeneoIS(len(mult), mult.ctypes.data_as(L.c_int_p)), inter))
+
     def init(self, nbDOF, nbDOFLoc, pcMap, pcA, pcADirLoc, pcB, pcX0, dofIdxDomLoc, dofIdxMultLoc,
              intersectLoc=None):
         """initGenEOPC (hdr/geneo.hpp:30-35): one subdomain for this rank.  pcB: DeviceVector or None."""

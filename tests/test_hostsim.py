@@ -229,3 +229,30 @@ def test_large_coarse_operator_blocked_cholesky(lib):
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "39", "-ksp_type", "cg"] + TIGHT
     _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv)
     assert info["dimE"] == 312
+
+
+@pytest.mark.parametrize("style", ["PCGenEOSetup", "initGenEOPC"])
+def test_reference_style_entry_points_one_subdomain_per_rank(lib, style):
+    """The two entry styles of the reference (hdr/geneo_c.h:10 PCGenEOSetup after KSPSetOperators(MATIS);
+    hdr/geneo.hpp:30 initGenEOPC): one subdomain = this rank's whole share.  On one rank the subdomain is the
+    domain: no overlap, Z from the pencil (A, A) -> a single Nicolaides-type vector or eigenvalues 1; M^-1 b must be
+    A^-1 b + Q b and the solve must return A^-1 b."""
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC
+    mesh = decomp.grid_mesh(size=6, dim=3)
+    a = decomp.global_matrix(mesh).tocsr()
+    n = a.shape[0]
+    b = decomp.rhs_default(a)
+    pc = GenEOPC(lib)
+    pc.set_from_options(["-geneo_lvl", "ASM,0", "-ksp_type", "cg", "-ksp_rtol", "1e-10"])
+    if style == "PCGenEOSetup":
+        pc.setup_from_operators(n, np.arange(n), a, np.ones(n, dtype=np.int32), None, [np.zeros(0, dtype=np.int32)])
+    else:
+        pc.init(n, n, np.arange(n), a, None, None, None, np.arange(n), np.ones(n, dtype=np.uint32), [[]])
+    pc.setup(b)
+    x, its, rnorm, reason = pc.solve(b)
+    assert reason.startswith("KSP_CONVERGED") and its <= 3            # the "preconditioner" is A^-1 itself
+    np.testing.assert_allclose(x, np.arange(1.0, n + 1.0), rtol=1e-8)
+    y = pc.apply(b)
+    np.testing.assert_allclose(y, np.arange(1.0, n + 1.0), rtol=1e-8)
+    pc.destroy()
