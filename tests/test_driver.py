@@ -76,3 +76,27 @@ def test_inp_lib_plugin_abi(tmp_path):
                            "-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "4", "-ksp_type", "cg"],
                           lib=lib, out=io.StringIO())
     assert lines[0].startswith("INFO: nb DOFs 512, nb elements 1408,") and "converged" in lines[-1]
+
+
+def test_inp_file_b_and_verbose(tmp_path):
+    """--inpFileB (idx [value] lines, driver:841-858) and --verbose 1 ("The solution X is:" block of the goldens)."""
+    d = dc.load()
+    rec = [r for r in dc.geneo_refs() if r["use_b_file"] and r["geneo_lvl"].startswith("ASM")][0]      # identity.inp + B.inp
+    inp = tmp_path / "A.inp"
+    inp.write_text(d["inputs"][rec["input"] + ".inp"])
+    bf = tmp_path / "B.inp"
+    bf.write_text(d["inputs"]["B.inp"])
+    ep, npart = dc.partition_for(rec)
+    pf = tmp_path / "part.txt"
+    part = ep if rec["metis"] == "dual" else npart
+    pf.write_text("\n".join(str(v) for v in part))
+    argv = ["--inpFileA", str(inp), "--inpFileB", str(bf), "--inpEps", str(rec["inpEps"]), "--np", "2", "--partFile", str(pf),
+            "--metisDual" if rec["metis"] == "dual" else "--metisNodal", "--addOverlap", str(rec["overlap"]), "--verbose", "1",
+            "-geneo_lvl", rec["geneo_lvl"], "-ksp_rtol", "1e-12", "-ksp_atol", "1e-12"]
+    if rec["geneo_cut"] > 0:
+        argv += ["-geneo_cut", str(rec["geneo_cut"])]
+    lines, x = driver.run(argv, lib=hu.hostsim_lib(), out=io.StringIO())
+    i = lines.index("The solution X is:")
+    printed = np.array([float(v) for v in lines[i + 1:i + 1 + len(rec["x"])]])
+    np.testing.assert_allclose(printed, rec["x"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x, rec["x"], rtol=1e-5, atol=1e-6)
