@@ -109,11 +109,11 @@ def test_solution_1e10(lib):
     assert np.linalg.norm(x - exact) <= 1e-10 * np.linalg.norm(exact)
 
 
-@pytest.mark.parametrize("rec", [r for r in dc.geneo_refs() if r["geneo_lvl"].startswith("ASM")],
+@pytest.mark.parametrize("rec", dc.geneo_refs(),
                          ids=lambda r: r["file"][:-4])
 def test_dummy_goldens_on_gpu(lib, rec):
-    """The reference's own tst/dummy goldens (GenEO-1 / ASM rows) through the HIP library: local
-    matrices in, converged solution out (to PETSc print precision)."""
+    """The reference's own tst/dummy goldens -- all 80 GenEO rows: ASM,0/1/H1/E1 and SORAS,0/2/H2/E2 -- through the HIP
+    library: local matrices in, converged solution out (to PETSc print precision)."""
     from geneo4petsc_amd import decomp
     from geneo4petsc_amd.pc import GenEOPC
     d = dc.load()
