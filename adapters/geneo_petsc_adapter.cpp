@@ -6,11 +6,13 @@
 //
 // NOT compiled in this repository: it needs PETSc >= 3.10 (petsc.h, petsc/private/pcimpl.h), which neither the build
 // container nor the GPU box has.  It only uses the C ABI of include/geneo_c.h; INTEGRATION.md walks through it.
-// Build (with PETSc):  mpicxx -std=c++11 -DPC=GeneoPC -I$PETSC_DIR/include -I<this repo>/include -c geneo_petsc_adapter.cpp
+// Build (with PETSc):  mpicxx -std=c++11 -I$PETSC_DIR/include -I<this repo>/include -c geneo_petsc_adapter.cpp
 #include <petsc.h>
 #include <petsc/private/pcimpl.h>          // pc->data, pc->ops (as the reference does, hdr/geneo.hpp:5)
 #include <hip/hip_runtime.h>
-#include "geneo_c.h"                       // from this repository (rename its PC typedef: -DPC=GeneoPC)
+#include <vector>
+#define GENEO_HAVE_PETSC                      // PETSc's PC / PetscErrorCode stay PETSc's; our handle is GeneoPC
+#include "geneo_c.h"                       // from this repository
 
 struct Bridge { GeneoPC h; Mat A; PetscInt n; double *xd, *yd; };
 
@@ -73,5 +75,5 @@ extern "C" PetscErrorCode PCGenEOSetup(PC pc, Mat pcADirLoc, IS mult, IS* inter)
   std::vector<GeneoIS> in;                                        // GenEO-2 reads the emptiness of each list
   if (inter) { PetscMPIInt P; MPI_Comm_size(PETSC_COMM_WORLD, &P);
     for (int q = 0; q < P; ++q) { PetscInt k; ISGetLocalSize(inter[q], &k); in.push_back({(int)k, NULL}); } }
-  return PCGenEOSetup(b->h, pcADirLoc ? &dir : NULL, im, inter ? in.data() : NULL);
+  return PCGenEOSetupViews(b->h, pcADirLoc ? &dir : NULL, im, inter ? in.data() : NULL);
 }

@@ -49,6 +49,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 SYMBOLS = {
     "PCCreate_GenEO": (C.c_int, [C.POINTER(C.c_void_p)]),
     "createGenEOPC": (C.c_int, [C.c_void_p]),
+    "PCGenEOCreateContext": (C.c_int, [C.c_void_p]),
     "PCDestroy_GenEO": (C.c_int, [C.POINTER(C.c_void_p)]),
     "PCSetFromOptions_GenEO": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]),
     "PCGenEOSetOption": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
@@ -58,6 +59,7 @@ SYMBOLS = {
     "usageGenEO_c": (C.c_char_p, []),
     "PCSetOperators_GenEO": (C.c_int, [C.c_void_p, C.POINTER(GeneoMatIS)]),
     "PCGenEOSetup": (C.c_int, [C.c_void_p, C.POINTER(GeneoCsr), GeneoIS, C.POINTER(GeneoIS)]),
+    "PCGenEOSetupViews": (C.c_int, [C.c_void_p, C.POINTER(GeneoCsr), GeneoIS, C.POINTER(GeneoIS)]),
     "initGenEOPC_c": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, c_int_p, C.POINTER(GeneoCsr),
                                 C.POINTER(GeneoCsr), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]),
     "PCGenEOSetSizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -54,6 +54,7 @@ PetscErrorCode PCCreate_GenEO(PC* pc) {
   return createGenEOPC(*pc);
 }
 
+PetscErrorCode PCGenEOCreateContext(PC pc) { return createGenEOPC(pc); }
 PetscErrorCode createGenEOPC(PC pc) {
   if (!pc) return 1;  // "GenEO preconditioner is invalid"
   delete pc->ctx;
@@ -193,6 +194,9 @@ PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int n, const int* map, const 
   GUARD_END(pc)
 }
 
+PetscErrorCode PCGenEOSetupViews(PC pc, const GeneoCsr* pcADirLoc, GeneoIS mults, const GeneoIS* inters) {
+  return PCGenEOSetup(pc, pcADirLoc, mults, inters);
+}
 PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS mults, const GeneoIS* inters) {
   if (!pc || !pc->ctx) return 1;
   if (!pc->has_ops) return pcfail(pc, "GenEO preconditioner: PCSetOperators_GenEO must be called first");

@@ -36,8 +36,17 @@
 extern "C" {
 #endif
 
+/* The handle.  Stand-alone it carries PETSc's names (PC, PetscErrorCode) so that host code reads like the reference's.
+ * Next to the real PETSc headers (adapters/geneo_petsc_adapter.cpp) define GENEO_HAVE_PETSC before including this file:
+ * PETSc's own PC / PetscErrorCode are then left alone and the handle is called GeneoPC. */
+#ifdef GENEO_HAVE_PETSC
+typedef struct _p_GeneoPC* GeneoPC;
+#define GENEO_PC GeneoPC
+#else
 typedef int PetscErrorCode;
 typedef struct _p_GeneoPC* PC;         /* stands for PETSc's PC */
+#define GENEO_PC PC
+#endif
 
 typedef struct {                       /* stands for a SEQAIJ Mat: host CSR view */
   int n;                               /* rows = cols */
@@ -60,50 +69,60 @@ typedef struct {                       /* stands for the MATIS operator (driver:
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 /* PCCreate + PCSetType(pc,"geneo"): allocates the PC shell, then calls createGenEOPC on it. */
-PetscErrorCode PCCreate_GenEO(PC* pc);
+PetscErrorCode PCCreate_GenEO(GENEO_PC* pc);
 /* src/geneo.cpp:2639-2728: (re)creates the context with the reference's default parameters. */
-PetscErrorCode createGenEOPC(PC pc);
+#ifndef GENEO_HAVE_PETSC
+PetscErrorCode createGenEOPC(GENEO_PC pc);
+#endif
+/* The same entry under a name of its own.  A PETSc-side adapter defines the reference's createGenEOPC(PC) and
+ * PCGenEOSetup(PC, Mat, IS, IS*) with PETSc's types (that is what the reference's driver links against) and forwards
+ * to these two; with GENEO_HAVE_PETSC the header therefore does not declare the reference-named pair. */
+PetscErrorCode PCGenEOCreateContext(GENEO_PC pc);
 /* src/geneo.cpp:2180-2243 */
-PetscErrorCode PCDestroy_GenEO(PC* pc);
+PetscErrorCode PCDestroy_GenEO(GENEO_PC* pc);
 
 /* ---- options (src/geneo.cpp:2329-2514) -------------------------------------------------- */
 /* Parses the -geneo_* options (same spellings, defaults, validation), plus the subset of the
  * forwarded prefixes this build understands: -els2_eps_{tol,nev,max_it,block,seed},
  * -els2_cheb_{degree,ratio}, -dls1_ksp_{rtol,max_it}, -ksp_{type,rtol,atol,divtol,max_it},
  * -ksp_gmres_restart.  Unknown options are ignored, like PETSc with -options_left no. */
-PetscErrorCode PCSetFromOptions_GenEO(PC pc, int argc, const char* const* argv);
-PetscErrorCode PCGenEOSetOption(PC pc, const char* key, const char* value);
+PetscErrorCode PCSetFromOptions_GenEO(GENEO_PC pc, int argc, const char* const* argv);
+PetscErrorCode PCGenEOSetOption(GENEO_PC pc, const char* key, const char* value);
 /* buildGenEOName, src/geneo.cpp:2245-2268 ("geneo1ASM", "geneo1HASM", ...) */
-const char* PCGenEOGetName(PC pc);
-const char* PCGenEOGetError(PC pc);
+const char* PCGenEOGetName(GENEO_PC pc);
+const char* PCGenEOGetError(GENEO_PC pc);
 /* the parsed options as "key=value;..." (what the driver reads from the public geneoContext fields,
  * src/geneo4PETSc.cpp:928-989) */
-const char* PCGenEOGetOptionsString(PC pc);
+const char* PCGenEOGetOptionsString(GENEO_PC pc);
 /* usageGenEO, src/geneo.cpp:2274-2327 */
 const char* usageGenEO_c(void);
 
 /* ---- inputs ----------------------------------------------------------------------------- */
 /* KSPSetOperators(ksp, A, A) with A of type MATIS (required: src/geneo.cpp:1681). */
-PetscErrorCode PCSetOperators_GenEO(PC pc, const GeneoMatIS* A);
+PetscErrorCode PCSetOperators_GenEO(GENEO_PC pc, const GeneoMatIS* A);
 /* hdr/geneo_c.h:10, src/geneo.cpp:2518-2572: one subdomain per rank, operator taken from
  * PCSetOperators_GenEO; pcADirLoc may be NULL (built from A); dofIntersections may be NULL
  * (only its emptiness pattern is used, and only by GenEO-2). */
-PetscErrorCode PCGenEOSetup(PC pc, const GeneoCsr* pcADirLoc, GeneoIS dofMultiplicities,
+#ifndef GENEO_HAVE_PETSC
+PetscErrorCode PCGenEOSetup(GENEO_PC pc, const GeneoCsr* pcADirLoc, GeneoIS dofMultiplicities,
                             const GeneoIS* dofIntersections);
+#endif
+PetscErrorCode PCGenEOSetupViews(GENEO_PC pc, const GeneoCsr* pcADirLoc, GeneoIS dofMultiplicities,
+                                 const GeneoIS* dofIntersections);   /* = PCGenEOSetup, see PCGenEOCreateContext */
 /* C form of initGenEOPC (hdr/geneo.hpp:30-35, src/geneo.cpp:2591-2632). b_dev / x0_dev may be NULL. */
-PetscErrorCode initGenEOPC_c(PC pc, unsigned int nbDOF, unsigned int nbDOFLoc, const int* map,
+PetscErrorCode initGenEOPC_c(GENEO_PC pc, unsigned int nbDOF, unsigned int nbDOFLoc, const int* map,
                              const GeneoCsr* A_local, const GeneoCsr* ADirLoc, const double* b_dev,
                              double* x0_dev, const unsigned int* dofIdxMultLoc);
 
 /* Several subdomains on one rank / GPU (extension; gid = the MPI rank the reference would use). */
-PetscErrorCode PCGenEOSetSizes(PC pc, int nbDOF, int nbSubdomainsGlobal);
-PetscErrorCode PCGenEOAddSubdomain(PC pc, int gid, int nbDOFLoc, const int* map, const int* multiplicity,
+PetscErrorCode PCGenEOSetSizes(GENEO_PC pc, int nbDOF, int nbSubdomainsGlobal);
+PetscErrorCode PCGenEOAddSubdomain(GENEO_PC pc, int gid, int nbDOFLoc, const int* map, const int* multiplicity,
                                    const GeneoCsr* A_local, const GeneoCsr* ADirLoc);
 
 /* intersectLoc of initGenEOPC (hdr/geneo.hpp:34): nonempty[q] != 0 iff subdomain gid shares DOFs with
  * subdomain q.  Only GenEO-2's gamma_loc reads it (src/geneo.cpp:1139-1148); on one rank it is derived
  * from the maps when absent.  gid < 0 addresses the subdomain added last. */
-PetscErrorCode PCGenEOSetIntersect(PC pc, int gid, int nbSubdomainsGlobal, const int* nonempty);
+PetscErrorCode PCGenEOSetIntersect(GENEO_PC pc, int gid, int nbSubdomainsGlobal, const int* nonempty);
 
 /* ---- multi-rank plumbing (one process per GPU; the transport is supplied by the host) ----- */
 typedef int (*GeneoExchangeFn)(void* user, int reverse);  /* 0 = forward (owner -> halo), 1 = reverse */
@@ -113,7 +132,7 @@ typedef int (*GeneoAllreduceFn)(void* user, int n);       /* in-place sum of red
  * rank sends, grouped by destination (send_counts[q]).  The callbacks move send_dev -> recv_dev
  * with these counts (forward) or with the two count arrays swapped (reverse), on the stream given
  * to GeneoSetStream.  Buffers are device memory owned by the caller (>= max(sum send, sum recv)). */
-PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int* owned_gid, int n_halo,
+PetscErrorCode PCGenEOSetComm(GENEO_PC pc, int rank, int size, int n_owned, const int* owned_gid, int n_halo,
                               const int* halo_gid, const int* recv_counts, const int* send_counts,
                               const int* send_idx, GeneoExchangeFn exchange, GeneoAllreduceFn allreduce,
                               void* user, double* send_dev, double* recv_dev, double* red_dev, int red_capacity);
@@ -121,21 +140,21 @@ PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int*
  * contiguous) and the exchange callback honours the width passed in the upper bits of its flag
  * (flag = reverse | width << 1; width 0 means 1).  Lets the coarse operator E be assembled 32 columns per
  * exchange instead of one.  Default width 1. */
-PetscErrorCode PCGenEOSetCommWidth(PC pc, int max_width);
+PetscErrorCode PCGenEOSetCommWidth(GENEO_PC pc, int max_width);
 
 /* ---- PC operations (the PETSc ops table, src/geneo.cpp:2717-2720) ------------------------- */
-PetscErrorCode PCSetUp_GenEO(PC pc);                                   /* setUpGenEOPC :1672 */
-PetscErrorCode PCApply_GenEO(PC pc, const double* x_dev, double* y_dev); /* applyGenEOPC :2051 */
-PetscErrorCode PCGenEOApplyQ(PC pc, const double* x_dev, double* y_dev); /* applyQ :1435 */
-PetscErrorCode MatMult_GenEO(PC pc, const double* x_dev, double* y_dev); /* MatMult on the MATIS A */
+PetscErrorCode PCSetUp_GenEO(GENEO_PC pc);                                   /* setUpGenEOPC :1672 */
+PetscErrorCode PCApply_GenEO(GENEO_PC pc, const double* x_dev, double* y_dev); /* applyGenEOPC :2051 */
+PetscErrorCode PCGenEOApplyQ(GENEO_PC pc, const double* x_dev, double* y_dev); /* applyQ :1435 */
+PetscErrorCode MatMult_GenEO(GENEO_PC pc, const double* x_dev, double* y_dev); /* MatMult on the MATIS A */
 /* initial guess written by setup (src/geneo.cpp:1601-1607): Q b for the efficient hybrid, else 0 */
-PetscErrorCode PCGenEOGetX0(PC pc, double* x0_dev);
-PetscErrorCode PCGenEOSetRHS(PC pc, const double* b_dev);
+PetscErrorCode PCGenEOGetX0(GENEO_PC pc, double* x0_dev);
+PetscErrorCode PCGenEOSetRHS(GENEO_PC pc, const double* b_dev);
 
 /* ---- Krylov driver (counterpart of KSPSolve at src/geneo4PETSc.cpp:1240; PETSc's own KSP
  *      drives PCApply_GenEO instead when PETSc is present) ----------------------------------- */
-PetscErrorCode KSPSolve_GenEO(PC pc, const double* b_dev, double* x_dev, int* its, double* rnorm, int* reason);
-int PCGenEOGetResidualHistory(PC pc, double* hist, int cap);
+PetscErrorCode KSPSolve_GenEO(GENEO_PC pc, const double* b_dev, double* x_dev, int* its, double* rnorm, int* reason);
+int PCGenEOGetResidualHistory(GENEO_PC pc, double* hist, int cap);
 
 /* ---- public counters / timers of geneoContext (hdr/geneo.hpp:96-123) ----------------------- */
 typedef struct {
@@ -149,15 +168,15 @@ typedef struct {
   int amg_levels;                       /* levels of the inner AMG hierarchy (0 = not used) */
   double amg_operator_complexity, amgSetupTime;
 } GeneoInfo;
-PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* info);
+PetscErrorCode PCGenEOGetInfo(GENEO_PC pc, GeneoInfo* info);
 /* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */
-int PCGenEOGetEigenvalues(PC pc, int local_sub, double* vals, int cap);
-int PCGenEOGetCandidates(PC pc, int local_sub, double* vals, int cap);
+int PCGenEOGetEigenvalues(GENEO_PC pc, int local_sub, double* vals, int cap);
+int PCGenEOGetCandidates(GENEO_PC pc, int local_sub, double* vals, int cap);
 /* coarse operator E (dimE x dimE row-major); returns dimE */
-int PCGenEOGetE(PC pc, double* e, int cap);
-int PCGenEOGetLocalDims(PC pc, int* ksub_global, int cap);
+int PCGenEOGetE(GENEO_PC pc, double* e, int cap);
+int PCGenEOGetLocalDims(GENEO_PC pc, int* ksub_global, int cap);
 /* tau_loc / gamma_loc per local subdomain (getLocalGenEOTau / Gamma, src/geneo.cpp:1097-1232); returns the count */
-int PCGenEOGetLocalParams(PC pc, double* tau_loc, double* gamma_loc, int cap);
+int PCGenEOGetLocalParams(GENEO_PC pc, double* tau_loc, double* gamma_loc, int cap);
 
 /* ---- input plugins ------------------------------------------------------------------------------
  * The reference driver loads its operators from `--inpLibA lib.so#args` plugins exporting the C++ function

@@ -120,3 +120,20 @@ def test_header_is_plain_c99(tmp_path):
                    '  return PCCreate_GenEO(&pc) ? 1 : PCDestroy_GenEO(&pc); }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                            "-c", str(src), "-o", str(tmp_path / "cabi.o")])
+
+
+def test_header_coexists_with_petsc_names(tmp_path):
+    """With GENEO_HAVE_PETSC the header leaves PETSc's own `PC` / `PetscErrorCode` alone (the handle is GeneoPC), so
+    the adapter of INTEGRATION.md can include both.  One-line stand-ins for the two PETSc typedefs are enough to check
+    that nothing in the header clashes with them."""
+    import subprocess
+    src = tmp_path / "both.c"
+    src.write_text('typedef int PetscErrorCode; typedef struct _p_PC* PC;   /* what petsc.h declares */\n'
+                   '#define GENEO_HAVE_PETSC\n#include "geneo_c.h"\n'
+                   '/* the adapter defines the reference-named pair with PETSc types and forwards to the library: */\n'
+                   'PetscErrorCode createGenEOPC(PC petsc_pc) { GeneoPC h; (void)petsc_pc; return PCCreate_GenEO(&h); }\n'
+                   'PetscErrorCode PCGenEOSetup(PC petsc_pc, void* mat, void* is, void** iss) {\n'
+                   '  GeneoPC h = 0; GeneoIS m = {0, 0}; (void)petsc_pc; (void)mat; (void)is; (void)iss;\n'
+                   '  return PCGenEOSetupViews(h, 0, m, 0) + PCGenEOCreateContext(h); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "both.o")])
