@@ -14,7 +14,7 @@
 #define GENEO_HAVE_PETSC                      // PETSc's PC / PetscErrorCode stay PETSc's; our handle is GeneoPC
 #include "geneo_c.h"                       // from this repository
 
-struct Bridge { GeneoPC h; Mat A; PetscInt n; double *xd, *yd; };
+struct Bridge { GeneoPC h = NULL; PetscInt n = 0; double *xd = NULL, *yd = NULL; };   // n: capacity of xd / yd
 
 static PetscErrorCode csr_of(Mat seqaij, GeneoCsr* v) {         // zero-copy view of a SEQAIJ matrix
   const PetscInt *ia, *ja; PetscInt n; PetscBool ok; PetscScalar* a;
@@ -30,11 +30,14 @@ static PetscErrorCode setup(PC pc) {                             // ops->setup  
 }
 static PetscErrorCode apply(PC pc, Vec x, Vec y) {               // ops->apply  (geneo.cpp:2051)
   Bridge* b = (Bridge*)pc->data;
-  const PetscScalar* xa; PetscScalar* ya;
+  const PetscScalar* xa; PetscScalar* ya; PetscInt nown;
+  VecGetLocalSize(x, &nown);                                            // the rank's OWNED rows of the global Vec
+  if (nown > b->n) { hipFree(b->xd); hipFree(b->yd); b->n = nown;
+    hipMalloc(&b->xd, nown * sizeof(double)); hipMalloc(&b->yd, nown * sizeof(double)); }
   VecGetArrayRead(x, &xa); VecGetArray(y, &ya);
-  hipMemcpy(b->xd, xa, b->n * sizeof(double), hipMemcpyHostToDevice);   // PCIe copy: 2 x 8 B/DOF per apply;
+  hipMemcpy(b->xd, xa, nown * sizeof(double), hipMemcpyHostToDevice);   // PCIe copy: 2 x 8 B/DOF per apply;
   PetscErrorCode rc = PCApply_GenEO(b->h, b->xd, b->yd);                // with a HIP-enabled PETSc pass the
-  hipMemcpy(ya, b->yd, b->n * sizeof(double), hipMemcpyDeviceToHost);   // device arrays (VecHIPGetArray) instead
+  hipMemcpy(ya, b->yd, nown * sizeof(double), hipMemcpyDeviceToHost);   // device arrays (VecHIPGetArray) instead
   VecRestoreArrayRead(x, &xa); VecRestoreArray(y, &ya);
   return rc;
 }
@@ -71,9 +74,8 @@ extern "C" PetscErrorCode PCGenEOSetup(PC pc, Mat pcADirLoc, IS mult, IS* inter)
   GeneoCsr dir; if (pcADirLoc) csr_of(pcADirLoc, &dir);
   ISGetIndices(mult, &m);
   GeneoIS im = {(int)n, (const int*)m};
-  b->n = n; hipMalloc(&b->xd, n * sizeof(double)); hipMalloc(&b->yd, n * sizeof(double));
   std::vector<GeneoIS> in;                                        // GenEO-2 reads the emptiness of each list
-  if (inter) { PetscMPIInt P; MPI_Comm_size(PETSC_COMM_WORLD, &P);
-    for (int q = 0; q < P; ++q) { PetscInt k; ISGetLocalSize(inter[q], &k); in.push_back({(int)k, NULL}); } }
+  if (inter) { PetscMPIInt np; MPI_Comm_size(PETSC_COMM_WORLD, &np);
+    for (int q = 0; q < np; ++q) { PetscInt k; ISGetLocalSize(inter[q], &k); in.push_back({(int)k, NULL}); } }
   return PCGenEOSetupViews(b->h, pcADirLoc ? &dir : NULL, im, inter ? in.data() : NULL);
 }
