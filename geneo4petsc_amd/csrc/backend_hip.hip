@@ -1737,7 +1737,10 @@ __global__ __launch_bounds__(256) void k_blockmul_mfma(const int* __restrict__ c
                                                        double* __restrict__ Y, int ldy, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int p = 4 * P4;
-  constexpr int ldS = p + ((34 - (p % 32)) % 32);  // = 2 (mod 32)
+  // odd row stride: the 16 lanes of one ds_read_b64 group read 16 different rows at the same column, i.e. addresses
+  // r * ldS; with ldS odd their 16 bank pairs are all different (ldS = 2 mod 32 left 2-way conflicts: PMC showed 41 %
+  // of the LDS cycles in bank conflicts)
+  constexpr int ldS = p + 1;
   constexpr int NC = (p + 63) / 64;
   constexpr int SR = 32;                           // slab rows (2 row tiles)
   double* sS = smem;                               // SR x ldS
@@ -1823,7 +1826,7 @@ template <int P4>
 static void launch_blockmul(const Chunks& c, const double* S, int lds_, const double* C, int q, double* Y, int ldy,
                             bool accumulate) {
   constexpr int p = 4 * P4;
-  constexpr int ldS = p + ((34 - (p % 32)) % 32);
+  constexpr int ldS = p + 1;
   const size_t sm = sizeof(double) * (size_t)32 * ldS;
   static bool attr_done = false;
   if (sm > 64 * 1024 && !attr_done) {
