@@ -2,24 +2,34 @@
 """bench.py -- GenEO-PCG setup + solve on MI355X, BASELINE.json's metric.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 launched plainly (no RANK in the environment): this process touches no GPU; it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a child
+process and relays rank 0's JSON line and the exit code.  Under torchrun (RANK / WORLD_SIZE set) it is one rank per GPU.
 
 One "step" = one full pass of the hot path on the resident subdomain matrices:
     KSPSetUp  (setUpGenEOPC: level-1 set-up, LOBPCG eigensolves, Z, E = Z^T A Z, factorisation)
   + KSPSolve  (PCG, every iteration = MATIS SpMV + applyGenEOPC with coarse correction)
-Workload at N = 1 = BASELINE.json configs[1] size (126^3 = 2.0 M DoF 3-D Laplacian of the reference's
-tst/laplacian generator, 7-point) split into 8 overlapping subdomains on the one GPU so that the whole
-two-level method (eigensolves, coarse space, RAS/ASM apply) runs; weak scaling: N GPUs hold
-N * 126^3 DoF (8 subdomains per GPU), halo + all-reduce over RCCL.
 
-`value` = SpMV GB/s (the metric's bandwidth figure): algorithmic bytes of the CSR SpMV launches issued
-inside the timed steps / their HIP-event time on the launch stream, summed over ranks.  Setup and solve
-seconds are reported next to it (`setup_s`, `solve_s`, `ms_per_step` = their sum).
+Workloads (3-D 7-point Laplacian of the reference's tst/laplacian generator, kappa = 1, eps = 1e-4, overlap 2,
+-geneo_lvl SRAS,1 -geneo_cut 20, tau 0.35, PCG rtol 1e-5):
+  N = 1   BASELINE configs[1] size: 126^3 = 2.0 M DoF, split into 8 overlapping subdomains on the one GPU so that the
+          whole two-level method (eigensolves, coarse space, RAS apply) runs.
+  N > 1   the metric's configuration (BASELINE configs[2], SURVEY 8d "config 3"): 184^3 DoF per GPU, ONE subdomain per GPU
+          (--subdomains-per-gpu 1) -- N = 8 is 368^3 = 49.8 M DoF in 8 subdomains.  Weak scaling.  Halo exchange and
+          all-reduces over RCCL (C++ transport inside libgeneopc, csrc/comm_rccl.cpp).
+
+`value` = CSR SpMV GB/s (the metric's bandwidth figure): algorithmic bytes of the fine-level SpMV launches issued
+inside the timed steps / their HIP-event time on the launch stream, summed over ranks.  Setup and solve seconds are
+reported next to it (`setup_s`, `solve_s`; `ms_per_step` = wall clock of the K steps / K).  `roofline` describes the
+kernel that owns the largest share of the step; `roofline.kernels` lists every hot kernel class with its share.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,25 +39,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+FP64_MFMA_PEAK_TFS = 78.6  # AMD MI355X datasheet FP64 matrix (the guide's table has no FP64-MFMA row); DESIGN.md section 3
+KERNEL_CLASSES = [(0, "k_spmv_sell (fine-level CSR SpMV)", "hbm"), (1, "k_spmm_sell (fine-level SpMM, 32 columns)", "hbm"),
+                  (2, "k_gram_mfma (Rayleigh-Ritz Gram, FP64 MFMA)", "mfma"),
+                  (3, "k_blockmul_mfma (LOBPCG block update, FP64 MFMA)", "mfma")]
 
 
 def rank_grid(n_ranks):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n_ranks, (n_ranks, 1, 1))
 
 
-def build_problem(args, rank, size):
-    from geneo4petsc_amd import decomp
-    n = args.n if args.n else int(round((args.n_per_gpu ** 3 * size) ** (1.0 / 3.0)))
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-per-gpu", type=int, default=0,
+                    help="grid points per side per GPU; 0 = 126 at N = 1 (2.0 M DoF), 184 at N > 1 (N = 8: 368^3 = 49.8 M)")
+    ap.add_argument("--subdomains-per-gpu", type=int, default=0, choices=(0, 1, 8),
+                    help="0 = 8 at N = 1, 1 at N > 1 (the metric's 8 subdomains on 8 GPUs)")
+    ap.add_argument("--n", type=int, default=0, help="override the global grid side")
+    ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--lvl", default="SRAS,1", help="-geneo_lvl; SRAS keeps the RAS weighting and a CG-legal (symmetric) PC")
+    ap.add_argument("--tau", type=float, default=0.35)
+    ap.add_argument("--cut", type=int, default=20)
+    ap.add_argument("--eps-tol", type=float, default=1e-3, help="reference default, geneo.cpp:658")
+    ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc KSP default rtol")
+    ap.add_argument("--dls1-rtol", type=float, default=1e-6,
+                    help="relative tolerance of the inner (local) solves; 1e-6 leaves the outer PCG untouched at rtol 1e-5")
+    ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
+    ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
+    ap.add_argument("--pc-args", default="", help="further options for the PC")
+    ap.add_argument("--cpu-sample-n", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default=os.environ.get("GENEO_BENCH_COMM", "rccl"), choices=("rccl", "torch", "staged"),
+                    help="N > 1 transport: rccl = C++ ncclSend/Recv + ncclAllReduce inside libgeneopc (default); "
+                         "torch = torch.distributed callbacks; staged = host-staged gloo (ranks may share a GPU)")
+    return ap
+
+
+def geneo_argv(args):
+    return ["-geneo_lvl", args.lvl, "-geneo_tau", str(args.tau), "-geneo_cut", str(args.cut),
+            "-els2_eps_tol", str(args.eps_tol), "-ksp_type", "cg", "-ksp_rtol", str(args.rtol),
+            "-dls1_ksp_rtol", str(args.dls1_rtol), "-dls1_pc_type", args.dls1_pc, "-els2_pc_type", args.els2_pc] \
+        + args.pc_args.split()
+
+
+def workload(args, size):
+    """(global grid side n, subdomain grid `parts`, subdomain -> rank map, subdomains per GPU)"""
+    spg = args.subdomains_per_gpu or (8 if size == 1 else 1)
+    npg = args.n_per_gpu or (126 if size == 1 else 184)
+    n = args.n if args.n else int(round((npg ** 3 * size) ** (1.0 / 3.0)))
     rg = rank_grid(size)
-    parts = tuple(2 * r for r in rg)                 # 8 subdomains per GPU
+    f = 2 if spg == 8 else 1
+    parts = tuple(f * r for r in rg)
     nb = parts[0] * parts[1] * parts[2]
-    # subdomain (bi,bj,bk) -> rank of its 2x2x2 block
     sub_rank = np.zeros(nb, dtype=np.int64)
     for bk in range(parts[2]):
         for bj in range(parts[1]):
             for bi in range(parts[0]):
                 s = bi + parts[0] * (bj + parts[1] * bk)
-                sub_rank[s] = (bi // 2) + rg[0] * ((bj // 2) + rg[1] * (bk // 2))
+                sub_rank[s] = (bi // f) + rg[0] * ((bj // f) + rg[1] * (bk // f))
+    return n, parts, sub_rank, spg
+
+
+def build_problem(args, rank, size):
+    from geneo4petsc_amd import decomp
+    n, parts, sub_rank, spg = workload(args, size)
+    nb = len(sub_rank)
     my = [s for s in range(nb) if sub_rank[s] == rank]
     doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s) for s in my]
     plan = decomp.grid_rank_plan(n, 3, parts, args.overlap, sub_rank, rank, size, doms)
@@ -59,42 +118,44 @@ def build_problem(args, rank, size):
         rows = d.a_dir @ (d.l2g.astype(np.float64) + 1.0)
         sel = npart_of(d.l2g) == d.gid
         b[np.searchsorted(plan.owned, d.l2g[sel])] = rows[sel]
-    return n, nb, doms, plan, b
+    return n, nb, spg, doms, plan, b
 
 
-def cpu_baseline(args, doms):
-    """The oracle's CPU kernels / algorithm on this box's host cores (rank 0, bounded sample)."""
+def cpu_baseline(args, doms, lib):
+    """The oracle's CPU kernels / algorithm on this box's host cores (rank 0, N = 1, bounded sample).  The GenEO leg
+    also runs the GPU library on the SAME sample grid with the SAME options, so that the line carries both PCG
+    iteration counts side by side (`parity_sample`)."""
     import scipy.sparse as sp
     out = {"kind": "port", "unit": "GB/s"}
     # (1) CSR SpMV, C + OpenMP restatement of MatMult_SeqAIJ, on the same block-diagonal local matrix
     so = os.path.join(ROOT, "oracle", "liboracle_kernels.so")
     if not os.path.exists(so):
-        import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "csrc")])
-    lib = C.CDLL(so)
-    lib.oracle_num_threads.restype = C.c_int
+    olib = C.CDLL(so)
+    olib.oracle_num_threads.restype = C.c_int
     a = sp.block_diag([d.a_dir for d in doms], format="csr")
     rp, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
     x = np.random.default_rng(0).random(a.shape[0])
     y = np.zeros(a.shape[0])
     args_c = (C.c_int(a.shape[0]), rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
               val.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
-    lib.oracle_csr_spmv(*args_c)
+    olib.oracle_csr_spmv(*args_c)
     reps = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 5.0 and reps < 400:
-        lib.oracle_csr_spmv(*args_c)
+        olib.oracle_csr_spmv(*args_c)
         reps += 1
     dt = (time.perf_counter() - t0) / max(1, reps)
     nbytes = a.nnz * 12 + (a.shape[0] + 1) * 4 + a.shape[0] * 16
     out["value"] = nbytes / dt / 1e9
-    out["cores"] = int(lib.oracle_num_threads())
+    out["cores"] = int(olib.oracle_num_threads())
     out["sample"] = "CSR SpMV of the same %d-row / %d-nnz local matrix, %d repetitions (C + OpenMP)" % (
         a.shape[0], a.nnz, reps)
-    # (2) the oracle's GenEO setup + PCG solve (SuperLU local solves, LAPACK/ARPACK eigensolves) on a
-    #     bounded sample of the same workload: same operator and options on a smaller grid
+    # (2) the oracle's GenEO setup + PCG solve (exact LU local solves, certified-exact eigenpairs) on a bounded sample
+    #     of the same workload -- same operator, same options, smaller grid -- and the GPU library beside it
     try:
         from geneo4petsc_amd import decomp
+        from geneo4petsc_amd.pc import GenEOPC
         from oracle import geneo_oracle as go
         ns = args.cpu_sample_n
         mesh = decomp.grid_mesh(n=ns, dim=3)
@@ -104,58 +165,109 @@ def cpu_baseline(args, doms):
         argv = geneo_argv(args)
         subs = [go.Subdomain(d.l2g, d.a_neu, d.mult, d.intersect) for d in dec.domains]
         t0 = time.perf_counter()
-        orc = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv)).setup(bs)
+        orc = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv))
+        orc.dense_limit, orc.exact_eigs = 4000, True
+        orc.setup(bs)
         t1 = time.perf_counter()
         res = go.solve(orc, bs, "cg", rtol=args.rtol)
         t2 = time.perf_counter()
         out["geneo_sample"] = {"grid": "%d^3 (%d DoF), 8 subdomains" % (ns, mesh.nbNode), "setup_s": t1 - t0,
                                "solve_s": t2 - t1, "iterations": res.its, "dimE": int(orc.dimE), "cores": 1}
+        pc = GenEOPC(lib)
+        pc.set_from_options(argv)
+        pc.set_sizes(mesh.nbNode, 8)
+        for d in dec.domains:
+            pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+        pc.setup(bs)
+        xg, gits, _, greason = pc.solve(bs)
+        gi = pc.info()
+        out["parity_sample"] = {"grid": "%d^3" % ns, "options": " ".join(argv),
+                                "oracle_iterations": int(res.its), "gpu_iterations": int(gits),
+                                "oracle_dimE": int(orc.dimE), "gpu_dimE": int(gi["dimE"]),
+                                "oracle_kept": [int(v) for v in orc.realDimELoc],
+                                "gpu_kept": [int(v) for v in pc.local_dims()],
+                                "solution_rel_diff": float(np.linalg.norm(xg - res.x) / np.linalg.norm(res.x)),
+                                "identical_counts": bool(int(res.its) == int(gits) and int(orc.dimE) == int(gi["dimE"])),
+                                "gpu_setup_s": gi["setupTime"], "gpu_solve_s": gi["solveTime"]}
+        pc.destroy()
     except Exception as e:     # the SpMV leg above is the contract; this leg is extra context
         out["geneo_sample"] = {"error": repr(e)}
     return out
 
 
-def geneo_argv(args):
-    return ["-geneo_lvl", args.lvl, "-geneo_tau", str(args.tau), "-geneo_cut", str(args.cut),
-            "-els2_eps_tol", str(args.eps_tol), "-ksp_type", "cg", "-ksp_rtol", str(args.rtol),
-            "-dls1_ksp_rtol", str(args.dls1_rtol), "-dls1_pc_type", args.dls1_pc, "-els2_pc_type", args.els2_pc] \
-        + args.pc_args.split()
+def spawn(args):
+    """N > 1 without torchrun: start the ranks as CHILD processes (this parent never touches the GPU) and relay."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_table(lib, step_ms_total, n_steps):
+    rows = []
+    for cls, name, bound in KERNEL_CLASSES:
+        ms, by, fl = C.c_double(0), C.c_double(0), C.c_double(0)
+        ns, nl = C.c_longlong(0), C.c_longlong(0)
+        lib.GeneoKernelProfileGet(cls, C.byref(ms), C.byref(by), C.byref(fl), C.byref(ns), C.byref(nl))
+        if ns.value == 0:
+            continue
+        avg = ms.value / ns.value
+        if bound == "hbm":
+            ach, peak, unit = by.value / ms.value * 1e-6, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = fl.value / ms.value * 1e-9, FP64_MFMA_PEAK_TFS, "TFLOP/s"
+        rows.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                     "avg_launch_ms": avg, "launches_timed": int(ns.value), "launches_total": int(nl.value),
+                     "algorithmic_bytes_per_launch": by.value / ns.value, "flops_per_launch": fl.value / ns.value,
+                     "hbm_GBs": by.value / ms.value * 1e-6,
+                     "share_of_step": avg * nl.value / max(step_ms_total, 1e-9)})
+    return rows
+
+
+def spmv_hbm_resident(lib, doms):
+    """The fine-level SpMV with its working set forced out of the 256 MiB Infinity Cache: a 640 MB stream between
+    launches (k_axpby on two 40 M-element vectors), HIP events around every SpMV."""
+    import scipy.sparse as sp
+    from geneo4petsc_amd.pc import Spmv, DeviceVector
+    a = sp.block_diag([d.a_dir for d in doms], format="csr")
+    h = Spmv(a, lib)
+    x = DeviceVector.from_host(lib, np.random.default_rng(0).random(a.shape[0]))
+    y = DeviceVector(lib, a.shape[0])
+    big = 40_000_000
+    u, v = DeviceVector.from_host(lib, np.ones(big)), DeviceVector.from_host(lib, np.ones(big))
+    lib.GeneoKernelProfileStart(1, C.c_double(1.0))
+    for _ in range(12):
+        lib.GeneoTestAxpby(u.ptr, v.ptr, C.c_double(0.5), C.c_double(0.5), big)
+        lib.GeneoSpmvApply(h.h, x.ptr, y.ptr)
+    lib.GeneoKernelProfileStop()
+    ms, by, ns = C.c_double(0), C.c_double(0), C.c_longlong(0)
+    lib.GeneoKernelProfileGet(0, C.byref(ms), C.byref(by), None, C.byref(ns), None)
+    for t in (x, y, u, v):
+        t.free()
+    h.destroy()
+    return {"GBs": by.value / max(ms.value, 1e-9) * 1e-6, "avg_launch_ms": ms.value / max(1, ns.value),
+            "launches_timed": int(ns.value), "working_set_bytes": by.value / max(1, ns.value),
+            "how": "640 MB evicting stream between launches"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-per-gpu", type=int, default=126, help="grid points per side per GPU (126^3 = 2.0 M DoF)")
-    ap.add_argument("--n", type=int, default=0, help="override the global grid side (e.g. 368 for the 50 M case)")
-    ap.add_argument("--overlap", type=int, default=2)
-    ap.add_argument("--lvl", default="SRAS,1", help="-geneo_lvl; SRAS keeps the RAS weighting and a CG-legal (symmetric) PC")
-    ap.add_argument("--tau", type=float, default=0.35)
-    ap.add_argument("--cut", type=int, default=20)
-    ap.add_argument("--eps-tol", type=float, default=1e-3, help="reference default, geneo.cpp:658")
-    ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc KSP default rtol")
-    ap.add_argument("--dls1-rtol", type=float, default=1e-6,
-                    help="relative tolerance of the inner (local) solves; 1e-6 leaves the outer PCG untouched at rtol 1e-5 "
-                         "(23 iterations and true residual 1.7814e-3 with 1e-6, 1e-8 and 1e-10 alike; 25 iterations with 1e-4)")
-    ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
-    ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
-    ap.add_argument("--pc-args", default="", help="further options for the PC, e.g. '-els2_amg_plain 1'")
-    ap.add_argument("--cpu-sample-n", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = build_parser().parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if size != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, size))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, size))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: the GenEO hot path has no CPU fallback")
-    # GENEO_BENCH_COMM=staged: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share
-    # devices, gloo + host-staged halo exchange); the driver's multi-GPU runs use RCCL (backend "nccl").
-    staged = os.environ.get("GENEO_BENCH_COMM") == "staged"
+    staged = args.comm == "staged"       # rehearsal with ranks sharing a GPU: gloo + host-staged halo exchange
     if staged:
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -174,67 +286,68 @@ def main():
     lib.GeneoSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     t_prep = time.perf_counter()
-    n, nb, doms, plan, b = build_problem(args, rank, size)
+    n, nb, spg, doms, plan, b = build_problem(args, rank, size)
     comm = None
+    comm_name = "none"
     if size > 1:
-        from geneo4petsc_amd.comm import TorchComm, StagedComm
-        comm = StagedComm(plan, lib) if staged else TorchComm(plan, torch.device("cuda", local_rank))
+        from geneo4petsc_amd import comm as gcomm
+        if staged:
+            comm, comm_name = gcomm.StagedComm(plan, lib), "staged (gloo, host copies)"
+        elif args.comm == "rccl":
+            comm, comm_name = gcomm.RcclComm(plan, lib, dist, torch.device("cuda", local_rank)), "rccl (C++ transport in libgeneopc)"
+        else:
+            comm, comm_name = gcomm.TorchComm(plan, torch.device("cuda", local_rank)), "torch.distributed (nccl backend)"
     prep_s = time.perf_counter() - t_prep
     argv = geneo_argv(args)
     bd = DeviceVector.from_host(lib, b)
 
-    def make_pc():
-        pc = GenEOPC(lib)
-        pc.set_from_options(argv)
-        pc.set_sizes(n ** 3, nb)
-        if comm is not None:
-            comm.attach(pc)
-        for d in doms:
-            pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
-        return pc
+    # ONE preconditioner object, set up again for every step (PCSetUp_GenEO releases the previous set-up first): the
+    # subdomain matrices are handed over once, as in the reference's initGenEOPC, and only one set-up is alive at a time
+    pc = GenEOPC(lib)
+    pc.set_from_options(argv)
+    pc.set_sizes(n ** 3, nb)
+    if comm is not None:
+        comm.attach(pc)
+    for d in doms:
+        pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(pc):
+    def step():
         pc.setup(bd)
         x, its, rnorm, reason = pc.solve(bd)
         info = pc.info()
         x.free()
         return its, reason, info
 
-    pcs = [make_pc() for _ in range(args.warmup + args.steps + 1)]
-    for i in range(args.warmup):
-        step(pcs[i])
-        pcs[i].destroy()
-    # roofline kernel = the CSR SpMV on the fine (subdomain) matrices; the small coarse-level launches of the
-    # inner AMG hierarchy use the same kernel but are latency-, not bandwidth-bound: time the fine ones only
-    fine_bytes = sum(d.a_dir.nnz for d in doms) * 12.0 + sum(len(d.l2g) for d in doms) * 20.0
-    lib.GeneoSpmvProfileStart(4, C.c_double(0.9 * fine_bytes))
+    for _ in range(args.warmup):
+        step()
+    # in-situ kernel timer: every 4th launch of each hot kernel class (fine-level SpMV / SpMM, MFMA Gram and update)
+    lib.GeneoKernelProfileStart(4, C.c_double(0.0))
     barrier()
     t0 = time.perf_counter()
     last = None
-    for i in range(args.warmup, args.warmup + args.steps):
-        last = step(pcs[i])
-        if i + 1 < args.warmup + args.steps:
-            pcs[i].destroy()
+    for _ in range(args.steps):
+        last = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    lib.GeneoKernelProfileStop()
+    its, reason, info = last
+    kernels = kernel_table(lib, 1e3 * elapsed, args.steps)
     ms_sum, by_sum = C.c_double(0), C.c_double(0)
     nsamp, nlaunch = C.c_longlong(0), C.c_longlong(0)
-    lib.GeneoSpmvProfileStop(C.byref(ms_sum), C.byref(by_sum), C.byref(nsamp), C.byref(nlaunch))
-    its, reason, info = last
+    lib.GeneoKernelProfileGet(0, C.byref(ms_sum), C.byref(by_sum), None, C.byref(nsamp), C.byref(nlaunch))
     # One more, UNTIMED step with the in-situ timer off: the inner PCG chunks then replay as HIP graphs (the timer
     # needs direct launches: HIP events cannot bracket kernels inside a graph), which is how the library runs
     # outside this benchmark.  Reported as information only.
-    pcs[-2].destroy()
-    pcs[-1].setup(bd)
-    xg, gits, _, greason = pcs[-1].solve(bd)
-    ginfo = pcs[-1].info()
+    pc.setup(bd)
+    xg, gits, _, greason = pc.solve(bd)
+    ginfo = pc.info()
     # true residual || A x - b || / || b || of that solve (driver:1072-1087), owned rows, summed over the ranks
-    axg = pcs[-1].matmult(xg)
+    axg = pc.matmult(xg)
     rr = axg.to_host() - b
     num, den = float(rr @ rr), float(b @ b)
     xg.free()
@@ -245,9 +358,6 @@ def main():
         num, den = float(tt[0]), float(tt[1])
     true_res = (num / den) ** 0.5
     barrier()
-    pc = pcs[-1]
-    local = {"elapsed": elapsed, "spmv_ms": ms_sum.value, "spmv_bytes": by_sum.value, "setup": info["setupTime"],
-             "solve": info["solveTime"]}
     if dist is not None:
         t = torch.tensor([elapsed, info["setupTime"], info["solveTime"]], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,31 +368,56 @@ def main():
     else:
         setup_s, solve_s = info["setupTime"], info["solveTime"]
         agg_gbs = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
-    gbs_rank = local["spmv_bytes"] / max(local["spmv_ms"], 1e-9) * 1e-6
-    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, calibrated as the guide prescribes:
-    # scripts/pmc_spmv.py + pmc_report.py, result committed under profiles/); only quoted when this run's
-    # matrix is the profiled one
-    traffic, traffic_src = None, None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_spmv_hbm_traffic_pmc.json")))
-        kname = lib.GeneoSpmvKernelName().decode()
-        alg = by_sum.value / max(1, nsamp.value)
-        if kname in prof and abs(prof[kname]["algorithmic_bytes"] - alg) <= 0.01 * alg:
-            traffic = prof[kname]["traffic_bytes_corrected"]
-            traffic_src = "profiles/r01_spmv_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except Exception:
-        pass
+    gbs_rank = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
     if rank == 0:
+        spmv_ws = by_sum.value / max(1, nsamp.value)
+        cache_note = ("working set %.0f MB > 256 MiB Infinity Cache: HBM-resident" % (spmv_ws / 1e6)
+                      if spmv_ws > 256 * 2 ** 20 else
+                      "working set %.0f MB < 256 MiB Infinity Cache: this in-situ rate is cache-assisted, the HBM-resident "
+                      "rate of the same kernel and matrix is roofline.spmv_hbm_resident" % (spmv_ws / 1e6))
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x 2 / WRITE_SIZE, separate passes, as the guide
+        # prescribes; scripts/pmc_report.py, committed under profiles/) -- only quoted when the profiled launch is this one
+        traffic = {}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")))
+            for k in kernels:
+                key = k["kernel"].split(" ")[0]
+                if key in prof and abs(prof[key]["algorithmic_bytes"] - k["algorithmic_bytes_per_launch"]) <= \
+                        0.02 * k["algorithmic_bytes_per_launch"]:
+                    k["traffic"] = prof[key]["traffic_bytes_corrected"]
+                    traffic[key] = k["traffic"]
+        except Exception:
+            pass
+        dom = max(kernels, key=lambda k: k["share_of_step"]) if kernels else None
+        roof = {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "k_spmv_sell"}
+        if dom is not None:
+            roof = {"bound": "hbm", "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
+                    "traffic_source": "profiles/r02_hbm_traffic_pmc.json" if dom.get("traffic") else None,
+                    "kernel": dom["kernel"], "share_of_step": dom["share_of_step"],
+                    "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"],
+                    "launches_total": dom["launches_total"],
+                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                    "note": "dominant kernel = largest share of the step among the in-situ timed classes; its HBM "
+                            "bandwidth is quoted against the 8 TB/s spec peak (MFMA kernels also list their TFLOP/s "
+                            "fraction in kernels[]: they sit at the ridge)"}
+        roof["kernels"] = kernels
+        roof["spmv_in_situ"] = {"GBs": gbs_rank, "frac": gbs_rank / HBM_PEAK_GBS, "note": cache_note}
         out = {
             "metric": "GenEO-PCG setup+solve sec and SpMV GB/s, 3D Laplacian 50M DoF, 1/2/4/8 GPUs",
             "value": agg_gbs, "unit": "GB/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D 7-pt Laplacian (reference tst/laplacian generator, kappa=1, eps=1e-4), "
-                                   "%d^3 = %d DoF, %d subdomains (8 per GPU), overlap %d, -geneo_lvl %s, "
-                                   "-geneo_cut %d, tau %.2f, PCG rtol %.0e; N=1 is BASELINE configs[1] size (126^3)"
-                                   % (n, n ** 3, nb, args.overlap, args.lvl, args.cut, args.tau, args.rtol),
-                       "grid": n, "dof": n ** 3, "subdomains": nb, "overlap": args.overlap},
+            "config": {"workload": "3D 7-pt Laplacian (reference tst/laplacian generator, kappa=1, eps=1e-4; the reference has "
+                                   "no 27-pt generator), %d^3 = %d DoF, %d subdomains (%d per GPU), overlap %d, "
+                                   "-geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e; %s"
+                                   % (n, n ** 3, nb, spg, args.overlap, args.lvl, args.cut, args.tau, args.eps_tol, args.rtol,
+                                      "N=1: BASELINE configs[1] size (126^3 = 2.0 M DoF) in 8 subdomains on the one GPU"
+                                      if size == 1 else
+                                      "N>1: the metric's configuration, 184^3 DoF and one subdomain per GPU (N=8: 368^3 = 49.8 M)"),
+                       "grid": n, "dof": n ** 3, "subdomains": nb, "subdomains_per_gpu": spg, "overlap": args.overlap,
+                       "transport": comm_name},
             "setup_s": setup_s, "solve_s": solve_s, "setup_plus_solve_s": setup_s + solve_s,
             "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
             "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
@@ -294,18 +429,21 @@ def main():
                                                "iterations": gits, "true_residual": true_res},
             "solve_breakdown_s": {"local_solves": info["lvl1ApplyMinvTimeLoc"], "coarse_Zt": info["lvl2ApplyZtTimeLoc"],
                                   "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
-            "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs_rank / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": lib.GeneoSpmvKernelName().decode(), "launches_timed": int(nsamp.value),
-                         "launches_total": int(nlaunch.value),
-                         "avg_launch_ms": ms_sum.value / max(1, nsamp.value),
-                         "algorithmic_bytes_per_launch": by_sum.value / max(1, nsamp.value)},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, doms)
+        if size == 1 and not args.no_cpu_baseline:
+            try:
+                roof["spmv_hbm_resident"] = spmv_hbm_resident(lib, doms)
+                roof["spmv_hbm_resident"]["frac"] = roof["spmv_hbm_resident"]["GBs"] / HBM_PEAK_GBS
+            except Exception as e:
+                roof["spmv_hbm_resident"] = {"error": repr(e)}
+            out["cpu_baseline"] = cpu_baseline(args, doms, lib)
+            if "parity_sample" in out["cpu_baseline"]:
+                out["parity_sample"] = out["cpu_baseline"].pop("parity_sample")
         print(json.dumps(out), flush=True)
-    for p in pcs:
-        p.destroy()
+    pc.destroy()
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

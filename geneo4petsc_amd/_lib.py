@@ -68,6 +68,15 @@ SYMBOLS = {
     "PCGenEOSetComm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p,
                                  c_int_p, c_int_p, EXCHANGE_FN, ALLREDUCE_FN, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int]),
+    "GeneoRcclUniqueId": (C.c_int, [C.c_char_p]),
+    "GeneoRcclCreate": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "PCGenEOSetCommRccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p,
+                                     C.c_int]),
+    "GeneoRcclDestroy": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "GeneoRcclGetError": (C.c_char_p, []),
+    "GeneoRcclPlanBuffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "GeneoRcclPlanExchange": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "GeneoRcclPlanAllreduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "PCSetUp_GenEO": (C.c_int, [C.c_void_p]),
     "PCApply_GenEO": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "PCGenEOApplyQ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -106,7 +115,12 @@ SYMBOLS = {
     "GeneoSpmvDestroy": (C.c_int, [C.POINTER(C.c_void_p)]),
     "GeneoSpmvProfileStart": (C.c_int, [C.c_int, C.c_double]),
     "GeneoSpmvProfileStop": (C.c_int, [c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "GeneoKernelProfileStart": (C.c_int, [C.c_int, C.c_double]),
+    "GeneoKernelProfileStop": (C.c_int, []),
+    "GeneoKernelProfileGet": (C.c_int, [C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoSpmmApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "GeneoSpmmTime": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                      C.c_int, c_dbl_p]),
     "GeneoSpmmFused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_double]),
     "GeneoBlockKernel": (C.c_int, [C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p,

@@ -111,6 +111,46 @@ class StagedComm(TorchComm):
         pc.set_comm_width(self.WIDTH)
 
 
+class RcclComm:
+    """The library's own C++ transport over RCCL / xGMI (csrc/comm_rccl.cpp): ncclSend / ncclRecv groups for the halo,
+    ncclAllReduce for the reductions, on the library's stream -- no Python callback in the data path.  Python only
+    bootstraps: rank 0 makes the 128-byte unique id, torch.distributed (any backend) broadcasts it."""
+    WIDTH = 32
+
+    def __init__(self, plan, lib, dist=None, device=None):
+        import ctypes as C
+        self.lib, self.plan, self.error = lib, plan, None
+        ida = C.create_string_buffer(128)
+        if plan.rank == 0 and lib.GeneoRcclUniqueId(ida):
+            raise RuntimeError(lib.GeneoRcclGetError().decode())
+        if plan.size > 1:
+            import torch
+            t = torch.tensor(list(ida.raw), dtype=torch.uint8, device=device if device is not None else "cpu")
+            dist.broadcast(t, 0)
+            ida = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.h = C.c_void_p()
+        if lib.GeneoRcclCreate(ida, int(plan.rank), int(plan.size), C.byref(self.h)):
+            raise RuntimeError(lib.GeneoRcclGetError().decode())
+
+    def attach(self, pc):
+        import ctypes as C
+        p = self.plan
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        owned, halo = i32(p.owned), i32(p.halo_gid)
+        rc, sc, si = i32(p.recv_counts), i32(p.send_counts), i32(p.send_idx)
+        ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        if self.lib.PCGenEOSetCommRccl(pc.h, self.h, len(owned), ptr(owned), len(halo), ptr(halo), ptr(rc), ptr(sc), ptr(si),
+                                       self.WIDTH):
+            raise RuntimeError(self.lib.GeneoRcclGetError().decode())
+        pc.n_owned = len(owned)
+        pc.rank = int(p.rank)
+
+    def close(self):
+        import ctypes as C
+        if self.h:
+            self.lib.GeneoRcclDestroy(C.byref(self.h))
+
+
 def gather_owned(x_owned, plan, n_global):
     """Test helper: assemble a global numpy vector from every rank's owned part."""
     import torch

@@ -49,6 +49,11 @@ struct Csr {
   int* long_rows = nullptr;    // rows handled by the long-row kernel
   int nlong = 0;
   int64_t sl_nnz = 0;          // stored entries incl. padding
+  // sliced SpMM traversal: sched[i] = i-th slice to process (nullptr: natural order); the XCD group g of the persistent
+  // grid walks the schedule entries xcd_ptr[g] .. xcd_ptr[g + 1]
+  int* sched = nullptr;        // nslice
+  int* xcd_ptr = nullptr;      // 9
+  bool fine = false;           // a subdomain-level (fine) operator: its launches are the ones bench.py's in-situ timer samples
   int vec_lpr = 0;             // > 0: long / ragged rows (restriction, coarse Galerkin operators): the SpMV runs the
                                // lanes-per-row CSR kernel with this many lanes per row instead of the slices
 };
@@ -74,6 +79,11 @@ void spmv(const Csr& a, const double* x, double* y);                    // y = A
 // bracketed by two HIP events on the backend stream (no host sync until stop).
 void spmv_profile_start(int every, double min_bytes);   // only launches moving >= min_bytes algorithmic bytes
 void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
+// all kernel classes at once: fine-level SpMV / SpMM (Csr::fine), MFMA Gram and block update (p, q >= 32)
+enum { PROF_SPMV = 0, PROF_SPMM = 1, PROF_GRAM = 2, PROF_BLOCKMUL = 3, PROF_NCLASS = 4 };
+void kernel_profile_start(int every, double spmv_min_bytes);
+void kernel_profile_stop();
+void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flops_sum, long long* nsampled, long long* nlaunch);
 bool spmv_profiling();   // between start and stop (callers replay one graph in eight as direct launches so that they are sampled)
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
@@ -203,6 +213,7 @@ int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as
 void* event_create();
 void  event_record(void* ev);
 float event_elapsed_ms(void* a, void* b);   // syncs on b
+void  event_destroy(void* ev);
 double hash_unit_host(uint64_t seed, uint64_t gid, uint64_t row, uint64_t colj);
 
 }  // namespace bk

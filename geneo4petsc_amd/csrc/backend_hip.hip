@@ -60,8 +60,11 @@ void* alloc(size_t bytes) {
   if (bytes == 0) bytes = 8;
   auto t0 = std::chrono::high_resolution_clock::now();
   HIPCHK(hipMalloc(&p, bytes));
-  g_alloc_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  g_alloc_s += dt;
   ++g_alloc_n;
+  static const bool trace = getenv("GENEO_ALLOC_TRACE") != nullptr;
+  if (trace && dt > 2e-4) fprintf(stderr, "[alloc] %.1f MB in %.3f ms\n", bytes / 1e6, dt * 1e3);
   HIPCHK(hipMemsetAsync(p, 0, bytes, g_stream));
   return p;
 }
@@ -327,6 +330,12 @@ static void finish_layout(Csr& a, const int* h_rowptr) {
     if (ns > 0)
       hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, g_stream, a.rowptr, a.col, a.val, n, ns,
                          a.sl_ptr, a.sl_col, a.sl_val, long_len);
+    {   // traversal of the sliced SpMM: eight contiguous ranges of the slice schedule, one per XCD group
+      int xp[9];
+      for (int g = 0; g <= 8; ++g) xp[g] = (int)(((int64_t)ns * g) / 8);
+      a.xcd_ptr = (int*)alloc(sizeof(int) * 9);
+      h2d(a.xcd_ptr, xp, sizeof(int) * 9);
+    }
     a.nlong = (int)longr.size();
     // Long or ragged rows (restriction operators, coarse Galerkin matrices): one lane group per row reads the
     // row coalesced and reduces with shuffles; the slices would pad every 64-row slice to its longest row.
@@ -369,6 +378,8 @@ Csr csr_remap_columns(const Csr& a, const int* map_dev) {
   if (a.sl_nnz > 0)
     hipLaunchKernelGGL(k_map_int, dim3(gridv(a.sl_nnz)), dim3(256), 0, g_stream, b.sl_col, a.sl_col, map_dev, a.sl_nnz);
   b.long_rows = (int*)dup(a.long_rows, sizeof(int) * std::max<size_t>(1, (size_t)a.nlong));
+  b.sched = a.sched ? (int*)dup(a.sched, sizeof(int) * std::max<size_t>(1, (size_t)a.nslice)) : nullptr;
+  b.xcd_ptr = a.xcd_ptr ? (int*)dup(a.xcd_ptr, sizeof(int) * 9) : nullptr;
   return b;
 }
 // =============================================================================== sparse products (multigrid set-up)
@@ -624,6 +635,7 @@ void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, do
 void csr_free(Csr& a) {
   dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
   dfree(a.sl_ptr); dfree(a.sl_col); dfree(a.sl_val); dfree(a.long_rows);
+  dfree(a.sched); dfree(a.xcd_ptr);
   a = Csr();
 }
 
@@ -843,54 +855,86 @@ void set_spmv_kind(int kind) {
   g_sell_variant = kind / 10;
 }
 
-struct SpmvProf {
-  bool on = false;
-  int every = 1;
-  double min_bytes = 0.0;
+// In-situ kernel timing (bench.py): while profiling is on, every `every`-th launch of each kernel class is bracketed by
+// two HIP events on the launch stream; nothing waits on the host until stop.  Classes (backend.h): fine-level CSR
+// SpMV, fine-level SpMM, MFMA Gram, MFMA block update.
+struct KProf {
   long long nlaunch = 0;
   std::vector<hipEvent_t> e0, e1;
-  std::vector<double> bytes;
+  std::vector<double> bytes, flops;
 };
-static SpmvProf g_prof;
-void spmv_profile_start(int every, double min_bytes) {
-  g_prof.on = true;
-  g_prof.min_bytes = min_bytes;
-  g_prof.every = every < 1 ? 1 : every;
-  g_prof.nlaunch = 0;
-  g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
+static bool g_prof_on = false;
+static int g_prof_every = 1;
+static double g_prof_min_bytes = 0.0;
+static KProf g_kprof[PROF_NCLASS];
+struct ProfScope {   // e0 at construction, e1 at destruction, when this launch is one of the sampled ones
+  KProf* k = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int cls, bool counted, double bytes, double flops) {
+    if (!g_prof_on || g_capturing || !counted) return;
+    KProf& kp = g_kprof[cls];
+    if (kp.nlaunch++ % g_prof_every != 0 || kp.e0.size() >= 20000) return;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, g_stream));
+    k = &kp;
+    kp.bytes.push_back(bytes);
+    kp.flops.push_back(flops);
+  }
+  ~ProfScope() {
+    if (!k) return;
+    (void)hipEventRecord(b, g_stream);
+    k->e0.push_back(a);
+    k->e1.push_back(b);
+  }
+};
+static void kprof_clear(KProf& k) {
+  for (hipEvent_t e : k.e0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : k.e1) (void)hipEventDestroy(e);
+  k.e0.clear(); k.e1.clear(); k.bytes.clear(); k.flops.clear();
+  k.nlaunch = 0;
 }
-bool spmv_profiling() { return g_prof.on; }
-void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
-  g_prof.on = false;
-  double ms = 0.0, by = 0.0;
+void kernel_profile_start(int every, double spmv_min_bytes) {
+  for (KProf& k : g_kprof) kprof_clear(k);
+  g_prof_on = true;
+  g_prof_every = every < 1 ? 1 : every;
+  g_prof_min_bytes = spmv_min_bytes;
+}
+void kernel_profile_stop() {
+  g_prof_on = false;
   HIPCHK(hipStreamSynchronize(g_stream));
-  for (size_t i = 0; i < g_prof.e0.size(); ++i) {
+}
+void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flops_sum, long long* nsampled,
+                        long long* nlaunch) {
+  double ms = 0.0, by = 0.0, fl = 0.0;
+  if (cls < 0 || cls >= PROF_NCLASS) throw std::runtime_error("kernel_profile_get: unknown class");
+  KProf& k = g_kprof[cls];
+  for (size_t i = 0; i < k.e1.size(); ++i) {
     float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, g_prof.e0[i], g_prof.e1[i]));
+    HIPCHK(hipEventElapsedTime(&t, k.e0[i], k.e1[i]));
     ms += t;
-    by += g_prof.bytes[i];
-    (void)hipEventDestroy(g_prof.e0[i]);
-    (void)hipEventDestroy(g_prof.e1[i]);
+    by += k.bytes[i];
+    fl += k.flops[i];
   }
   if (ms_sum) *ms_sum = ms;
   if (bytes_sum) *bytes_sum = by;
-  if (nsampled) *nsampled = (long long)g_prof.e0.size();
-  if (nlaunch) *nlaunch = g_prof.nlaunch;
-  g_prof.e0.clear(); g_prof.e1.clear(); g_prof.bytes.clear();
+  if (flops_sum) *flops_sum = fl;
+  if (nsampled) *nsampled = (long long)k.e1.size();
+  if (nlaunch) *nlaunch = k.nlaunch;
+}
+void spmv_profile_start(int every, double min_bytes) { kernel_profile_start(every, min_bytes); }
+bool spmv_profiling() { return g_prof_on; }
+void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
+  kernel_profile_stop();
+  kernel_profile_get(PROF_SPMV, ms_sum, bytes_sum, nullptr, nsampled, nlaunch);
 }
 
 void spmv(const Csr& a, const double* x, double* y) {
   if (a.n == 0) return;
   const int per = (a.nblk + 7) / 8;
+  // algorithmic bytes: nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)
   const double abytes = (double)a.nnz * 12.0 + ((double)a.n + 1.0) * 4.0 + (double)a.n * 16.0;
-  const bool sample = g_prof.on && !g_capturing && abytes >= g_prof.min_bytes && (g_prof.nlaunch++ % g_prof.every == 0) &&
-                      g_prof.e0.size() < 20000;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (sample) {
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, g_stream));
-  }
+  ProfScope prof(PROF_SPMV, a.fine || (g_prof_min_bytes > 0.0 && abytes >= g_prof_min_bytes), abytes, 2.0 * (double)a.nnz);
   if (spmv_kind() == 0) {
     if (!a.rowblk) throw std::runtime_error("spmv: matrix was uploaded without LDS row blocks (GENEO_SPMV=lds at upload)");
     hipLaunchKernelGGL(k_spmv_lds, dim3(per * 8), dim3(256), 0, g_stream, a.rowblk, a.nblk, a.rowptr,
@@ -921,13 +965,6 @@ void spmv(const Csr& a, const double* x, double* y) {
     if (a.nlong > 0)
       hipLaunchKernelGGL(k_spmv_long, dim3(a.nlong), dim3(256), 0, g_stream, a.long_rows, a.rowptr, a.col, a.val,
                          x, y);
-  }
-  if (sample) {
-    HIPCHK(hipEventRecord(e1, g_stream));
-    g_prof.e0.push_back(e0);
-    g_prof.e1.push_back(e1);
-    // algorithmic bytes: nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)
-    g_prof.bytes.push_back(abytes);
   }
 }
 
@@ -999,9 +1036,140 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
   }
 }
 
+// ------------------------------------------------------------------------------- sliced SpMM
+// Y = post .* (A (pre .* X)) on the 64-row slices, m = 2 LG columns.  LG lanes own one row (16 bytes = two columns per
+// lane), so ONE wave-wide dwordx4 load gathers the k-th neighbour rows of 64 / LG consecutive rows (m = 32: four rows,
+// 1 KiB per instruction) and the Y store of those rows is one contiguous 1 KiB segment.  The slice's (col, val) entries
+// are read ONCE, coalesced and non-temporal (lane = row of the slice, as the SpMV does), staged in a wave-private LDS
+// tile and handed to the row groups by broadcast reads: no dependent global load in front of the X gathers.
+//
+// Traversal: persistent grid; the hardware deals workgroups round-robin over the 8 XCDs, workgroup b belongs to XCD
+// group b & 7 and that group walks ITS OWN contiguous range of the slice schedule (xptr[g] .. xptr[g + 1]) with all its
+// waves side by side.  The rows of X a group touches at any time are the few hundred slices its waves hold plus their
+// neighbours: that window, not the whole block, is what the XCD's private 4 MiB L2 has to keep.  (Which XCD a group
+// lands on does not matter for correctness.)  sched == nullptr: slices in natural order.
+template <int LG, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
+                                                   const double* __restrict__ sl_val, int n,
+                                                   const int* __restrict__ sched, const int* __restrict__ xptr,
+                                                   const double* __restrict__ X, int ldx, double* __restrict__ Y, int ldy,
+                                                   const double* __restrict__ pre, const double* __restrict__ post,
+                                                   const double* __restrict__ B, int ldb, double* __restrict__ Z, int ldz,
+                                                   const double* __restrict__ dinv, double w) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int KC = 8;              // entries per row staged per chunk
+  constexpr int RS = 64 / LG;        // rows per wave-wide load
+  constexpr int NSTEP = 64 / RS;     // steps per slice
+  constexpr int U = (NSTEP < 4) ? NSTEP : 4;   // steps in flight
+  __shared__ int lc[4][KC * 64];
+  __shared__ double lv[4][KC * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / LG, q = lane % LG;
+  const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  int* mc = lc[wave];
+  double* mv = lv[wave];
+  for (int it = xptr[xg] + slot * 4 + wave; it < xptr[xg + 1]; it += wpx * 4) {
+    const int s = sched ? sched[it] : it;
+    const int64_t base = sl_ptr[s];
+    const int wd = (int)((sl_ptr[s + 1] - base) >> 6);
+    const int nchunk = (wd + KC - 1) / KC;
+    for (int g = 0; g < NSTEP / U; ++g) {
+      d2 acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = d2{0.0, 0.0};
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int kc = (wd - ch * KC < KC) ? wd - ch * KC : KC;
+        if (nchunk > 1 || g == 0) {          // narrow slices (the fine-level stencils) are staged once
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int k = 0; k < kc; ++k) {
+            const int64_t e = base + (int64_t)64 * (ch * KC + k) + lane;
+            const int c = __builtin_nontemporal_load(sl_col + e);
+            double v = __builtin_nontemporal_load(sl_val + e);
+            if (pre) v *= pre[c];
+            mc[k * 64 + lane] = c;
+            mv[k * 64 + lane] = v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          if (k < kc) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int rl = (g * U + u) * RS + grp;
+              const int c = mc[k * 64 + rl];
+              const double v = mv[k * 64 + rl];
+              const d2 x = *reinterpret_cast<const d2*>(X + (int64_t)c * ldx + 2 * q);
+              acc[u] += v * x;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
+        if (r >= n) continue;
+        d2 a2 = acc[u];
+        if (post) a2 *= post[r];
+        d2 out;
+        if (EPI == EPI_NONE) {
+          out = a2;
+        } else if (EPI == EPI_RES) {
+          out = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2;
+        } else if (EPI == EPI_ADD) {
+          out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) + a2;
+        } else if (EPI == EPI_JAC) {
+          out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
+                (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+        } else {  // EPI_PRE: X = B, pre = dinv
+          const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
+          *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
+          out = bb - w * a2;
+        }
+        __builtin_nontemporal_store(out, reinterpret_cast<d2*>(Y + r * ldy + 2 * q));
+      }
+    }
+  }
+}
+
+static int g_spmm_wpx = -1;      // workgroups per XCD group of the sliced SpMM (GENEO_SPMM_WPX; 0 = old CSR kernel)
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// true when the launch was taken by the sliced kernel
+template <int EPI>
+static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                             const double* post, const double* B, int ldb, double* Z, int ldz, const double* dinv,
+                             double w) {
+  if (g_spmm_wpx < 0) {
+    const char* e = getenv("GENEO_SPMM_WPX");
+    g_spmm_wpx = e ? atoi(e) : 128;   // measured at 126^3 (0.35 ms): 64 -> 0.43, 192 -> 0.39, 256 -> 0.41 ms
+  }
+  if (g_spmm_wpx == 0 || spmv_kind() != 1 || a.vec_lpr > 0 || a.nlong > 0 || !a.sl_ptr || !a.xcd_ptr) return false;
+  if (m != 16 && m != 32 && m != 64) return false;
+  if ((ldx | ldy | ldb | ldz) & 1) return false;
+  if (!aligned16(X) || !aligned16(Y) || !aligned16(B) || !aligned16(Z)) return false;
+  // small matrices: no more workgroups than there is work for (4 slices per workgroup and pass)
+  int wpx = g_spmm_wpx;
+  const int need = (a.nslice + 31) / 32;
+  if (wpx > need) wpx = need < 1 ? 1 : need;
+#define SELLMM(L)                                                                                                    \
+  hipLaunchKernelGGL((k_spmm_sell<L, EPI>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
+                     a.sched, a.xcd_ptr, X, ldx, Y, ldy, pre, post, B, ldb, Z, ldz, dinv, w)
+  if (m == 16) SELLMM(8);
+  else if (m == 32) SELLMM(16);
+  else SELLMM(32);
+#undef SELLMM
+  return true;
+}
+
 static void spmm_ld(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                     const double* post) {
   if (a.n == 0 || m == 0) return;
+  // algorithmic bytes: the matrix once, X once, Y once
+  ProfScope prof(PROF_SPMM, a.fine && m >= 16, (double)a.nnz * 12.0 + (double)a.n * 4.0 + 16.0 * m * (double)a.n,
+                 2.0 * (double)a.nnz * m);
+  if (spmm_sell_launch<EPI_NONE>(a, X, ldx, Y, ldy, m, pre, post, nullptr, 0, nullptr, 0, nullptr, 0.0)) return;
   if (m <= 16) {
     int g = std::min(grid1d(a.n, 16), 8192);
     hipLaunchKernelGGL(k_spmm<16>, dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, X, ldx, Y,
@@ -1043,6 +1211,11 @@ static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int 
   const double* Xin = (EPI == EPI_PRE) ? B : X;
   const int ldin = (EPI == EPI_PRE) ? ldb : ldx;
   const double* pre = (EPI == EPI_PRE) ? dinv : nullptr;
+  // + the epilogue's block reads / writes: RES, ADD one more block in, JAC two, PRE one more out
+  ProfScope prof(PROF_SPMM, a.fine && m >= 16,
+                 (double)a.nnz * 12.0 + (double)a.n * 4.0 + (16.0 + (EPI == EPI_JAC ? 16.0 : 8.0)) * m * (double)a.n,
+                 2.0 * (double)a.nnz * m);
+  if (spmm_sell_launch<EPI>(a, Xin, ldin, Y, ldy, m, pre, nullptr, B, ldb, Z, ldz, dinv, w)) return;
   if (m <= 16) {
     int g = std::min(grid1d(a.n, 16), 8192);
     hipLaunchKernelGGL((k_spmm<16, EPI>), dim3(g), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, Xin, ldin, Y,
@@ -1676,6 +1849,7 @@ void gram_plan_drop(const Chunks& c) {
 
 void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, int ldt_, int q, double* G) {
   if (c.nchunk == 0 || p == 0 || q == 0) return;
+  ProfScope prof(PROF_GRAM, p >= 32 && q >= 32, 8.0 * (double)c.n * (p + q), 2.0 * (double)c.n * p * q);
   GramPlan& pl = gram_plan(c);
   const size_t need = (size_t)pl.ngroup * p * q;
   if (pl.part_doubles < need) {
@@ -1840,6 +2014,7 @@ static void launch_blockmul(const Chunks& c, const double* S, int lds_, const do
 void block_mul(const Chunks& c, const double* S, int lds_, int p, const double* C, int q, double* Y, int ldy,
                bool accumulate) {
   if (c.nchunk == 0 || p == 0 || q == 0) return;
+  ProfScope prof(PROF_BLOCKMUL, p >= 32 && q >= 32, 8.0 * (double)c.n * (p + q), 2.0 * (double)c.n * p * q);
   const int Q16 = q / 16;
   const bool qok = (q % 16 == 0) && (Q16 == 1 || Q16 == 2 || (Q16 % 4 == 0));
   if (!g_no_mfma && qok && p % 4 == 0) {
@@ -2313,6 +2488,9 @@ float event_elapsed_ms(void* a, void* b) {
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b));
   return ms;
+}
+void event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }
 
 }  // namespace bk

@@ -242,6 +242,8 @@ PetscErrorCode PCGenEOSetComm(PC pc, int rank, int size, int n_owned, const int*
   if (!pc || !pc->ctx) return 1;
   geneo::PC* c = pc->ctx;
   if (size < 1 || rank < 0 || rank >= size) return pcfail(pc, "GenEO: bad communicator");
+  if (size > 1 && (red_capacity < 1 || !red_dev || !exchange || !allreduce))
+    return pcfail(pc, "GenEO: communicator needs both callbacks and a reduction buffer of at least one double");
   c->rank = rank;
   c->size = size;
   c->owned.assign(owned_gid, owned_gid + n_owned);
@@ -524,6 +526,8 @@ PetscErrorCode GeneoSpmvTime(GeneoSpmv h, const double* x, double* y, int reps, 
   for (int i = 0; i < reps; ++i) bk::spmv(h->a, x, y);
   bk::event_record(e1);
   const float ms = bk::event_elapsed_ms(e0, e1);
+  bk::event_destroy(e0);
+  bk::event_destroy(e1);
   if (ms_avg) *ms_avg = (double)ms / reps;
   GUARD_END((PC) nullptr)
   return 0;
@@ -538,6 +542,25 @@ PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long
   GUARD_END((PC) nullptr)
   return 0;
 }
+PetscErrorCode GeneoKernelProfileStart(int every, double spmv_min_bytes) {
+  GUARD_BEGIN
+  bk::kernel_profile_start(every, spmv_min_bytes);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoKernelProfileStop(void) {
+  GUARD_BEGIN
+  bk::kernel_profile_stop();
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoKernelProfileGet(int kernel_class, double* ms_sum, double* bytes_sum, double* flops_sum,
+                                     long long* nsampled, long long* nlaunch) {
+  GUARD_BEGIN
+  bk::kernel_profile_get(kernel_class, ms_sum, bytes_sum, flops_sum, nsampled, nlaunch);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
 PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h) {
   if (!h || !*h) return 0;
   bk::csr_free((*h)->a);
@@ -549,6 +572,27 @@ PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X, double* Y, int m, co
   if (!h) return 1;
   GUARD_BEGIN
   bk::spmm_strided(h->a, X, m, Y, m, m, pre, post);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
+// strided blocks + HIP-event timing of `reps` back-to-back launches (reps <= 0: one untimed launch)
+PetscErrorCode GeneoSpmmTime(GeneoSpmv h, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
+                             const double* post, int reps, double* ms_avg) {
+  if (!h) return 1;
+  GUARD_BEGIN
+  bk::spmm_strided(h->a, X, ldx, Y, ldy, m, pre, post);
+  if (reps > 0) {
+    void* e0 = bk::event_create();
+    void* e1 = bk::event_create();
+    bk::event_record(e0);
+    for (int i = 0; i < reps; ++i) bk::spmm_strided(h->a, X, ldx, Y, ldy, m, pre, post);
+    bk::event_record(e1);
+    const float ms = bk::event_elapsed_ms(e0, e1);
+    bk::event_destroy(e0);
+    bk::event_destroy(e1);
+    if (ms_avg) *ms_avg = (double)ms / reps;
+  }
   GUARD_END((PC) nullptr)
   return 0;
 }
@@ -624,6 +668,8 @@ PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const dou
   }
   bk::dfree(dS);
   bk::chunks_free(c);
+  bk::event_destroy(e0);
+  bk::event_destroy(e1);
   GUARD_END((PC) nullptr)
   return 0;
 }

@@ -119,6 +119,11 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   if (key == "-els2_eps_nev") return integer(o.eps_nev);
   if (key == "-els2_eps_max_it") return integer(o.eps_max_it);
   if (key == "-els2_eps_block") return integer(o.eps_block);
+  if (key == "-els2_eps_conv") {
+    if (value != "sinvert" && value != "residual") return "unsupported -els2_eps_conv " + value;
+    o.eps_conv = value;
+    return "";
+  }
   if (key == "-els2_cheb_degree") return integer(o.cheb_degree);
   if (key == "-els2_cheb_ratio") return dbl(o.cheb_ratio);
   if (key == "-els2_rr_drop") return dbl(o.rr_drop);
@@ -497,8 +502,11 @@ int PC::finish_amg1() {
 
 // ------------------------------------------------------------------------------------ setup
 int PC::setup(const double* b_dev) {
+  // a second set-up of the same PC (or a retry after a failed one) first releases everything the previous one
+  // allocated; the clock of setupTime starts after that release
+  free_all();
+  info = Info();
   auto t0 = clk::now();
-  if (is_setup) free_all();
   std::string err = validate_options(opt);
   if (!err.empty()) return fail(err);
   if (opt.lvl2 == 2 && !opt.lvl1ORAS)
@@ -537,6 +545,7 @@ int PC::setup(const double* b_dev) {
   };
   if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] %-28s %.3f s\n", "layout + Dirichlet + A_Neu blockdiag", secs(t0, tdbg));
   neuL = upload_host(h_neuL);
+  neuL.fine = true;
   lap("upload A_Neu");
   // same matrix with ext-space columns (l2e o col) for the MATIS MatMult, so that the gather R x is fused into the
   // SpMV; own copy (the sliced layout embeds the columns), made on the device from the one just uploaded
@@ -545,6 +554,7 @@ int PC::setup(const double* b_dev) {
   HostCsr h_dirL = make_blockdiag(lvl1, suboff, nullptr);
   lap("A_Dir blockdiag");
   dirL = upload_host(h_dirL);
+  dirL.fine = true;
   lap("upload A_Dir");
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {
@@ -1140,15 +1150,17 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   bool have_mask = false;
   double t_rr_host = 0.0, t_dev_wait = 0.0;
   auto t_lob0 = clk::now();
-  auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
-    // Gram blocks of the leading p columns
+  // Gram blocks of the leading p columns, symmetrised on the host
+  auto gram_blocks = [&](int p) {
     bk::gram(ch, S, p3, p, AS, p3, p, dGA);
     bk::gram(ch, S, p3, p, BS, p3, p, dGB);
     auto tg0 = clk::now();
     bk::d2h(hGA.data(), dGA, sizeof(double) * (size_t)ns * p * p);
     bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p * p);
+    t_dev_wait += secs(tg0, clk::now());
+  };
+  auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
     auto tg1 = clk::now();
-    t_dev_wait += secs(tg0, tg1);
     std::fill(hC.begin(), hC.end(), 0.0);
     auto rr_one = [&](int s) {
       std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
@@ -1199,6 +1211,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT);
     return 0;
   };
+  gram_blocks(m);
   rayleigh_ritz(m, 0, m, false);
   // P block := 0 (the swap left stale data there)
   bk::block_axpby(S + m, p3, 0.0, S + m, p3, 0.0, nL, m);
@@ -1208,10 +1221,76 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   const double tol = opt.eps_tol;
   const double lmax = P.lmax * 1.05, lmin = lmax / std::max(1.5, opt.cheb_ratio);
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  // Convergence test (-els2_eps_conv):
+  //   "sinvert" (default with the V-cycle preconditioner): ARPACK's test in the shift-invert mode the reference runs
+  //   (geneo.cpp:649-663, EPSSetTolerances tol at :658): Ritz estimate || OP x - theta x ||_B <= tol theta with
+  //   OP = A^-1 B, theta = 1 / lambda, i.e. || A^-1 (A x - lambda B x) ||_B <= tol ||x||_B.  The preconditioned residual
+  //   W = T r (T = one V-cycle ~ A^-1) is the next search direction anyway and its B-norm is on the diagonal of the Gram
+  //   block the Rayleigh-Ritz needs: the test costs nothing and no extra host round trip.
+  //   "residual": || r ||_2 <= tol (||A x||_2 + |lambda| ||B x||_2) (round 1; kept for the Chebyshev preconditioner,
+  //   which is no approximation of A^-1 on the smooth components, and for checks of B with A = identity).
+  const bool conv_sinvert = P.amg && opt.eps_conv != "residual";
   int it = 0;
   bool all_done = false;
   std::vector<int> nev_s(ns);
   for (int s = 0; s < ns; ++s) nev_s[s] = std::min(nev_try, (int)subs[s].l2g.size());
+  static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
+  std::vector<double> lam_prev((size_t)ns * m, 1e300);   // Ritz values of the previous iteration (straggler test)
+  // locks + frozen subdomains from res[][]; returns true when every subdomain is done
+  auto update_locks = [&]() {
+    bool done = true;
+    for (int s = 0; s < ns; ++s) {
+      if (frozen[s]) continue;
+      bool sub_done = true;
+      for (int j = 0; j < m; ++j) {
+        const size_t e = (size_t)s * m + j;
+        // soft locking: a converged pair stays in X (and in the Rayleigh-Ritz) but no longer
+        // contributes search directions -- its W / P columns would only inject rounding noise
+        if (lam[e] >= 1e299 || (res[s][j] <= tol && !nolock)) locked[e] = 1;
+        if (nolock && j < nev_s[s] && res[s][j] > tol) sub_done = false;
+        if (j < nev_s[s] && !locked[e]) sub_done = false;
+      }
+      // No straggler: a Ritz pair behind the wanted ones that has not converged may still be on its way to an
+      // eigenvalue BELOW the last wanted one (a late copy of a multiplet: symmetric subdomains have 3- and 6-fold
+      // ones) -- the wanted pairs would then all be converged eigenpairs, but not the lowest ones.  Sorted Ritz
+      // values only move down from one iteration to the next, so a pair is harmless when either
+      //   (a) its shift-invert estimate e_j brackets its eigenvalue above the last wanted one:
+      //       theta_j / (1 + e_j) > last (OP = A^-1 B is self-adjoint in the B inner product), or
+      //   (b) it has all but stopped moving: even 12 x its last step down (a geometric tail of ratio 0.92, slower
+      //       than any convergence seen on this pencil) leaves it above the last wanted one.
+      // Pairs inside the cluster of the last wanted value satisfy neither and have to converge themselves.
+      if (sub_done && conv_sinvert && !nolock && nev_s[s] >= 1 && nev_s[s] < m) {
+        const double last = lam[(size_t)s * m + nev_s[s] - 1] * (1.0 + tol);
+        for (int j = nev_s[s]; j < m; ++j) {
+          const size_t e = (size_t)s * m + j;
+          if (locked[e] || lam[e] >= 1e299) continue;
+          const double drop = (lam_prev[e] < 1e299) ? std::max(0.0, lam_prev[e] - lam[e]) : lam[e];
+          if (lam[e] / (1.0 + res[s][j]) > last) continue;
+          if (lam[e] - 12.0 * drop > last) continue;
+          sub_done = false;
+        }
+      }
+      if (sub_done) frozen[s] = 1;
+      else done = false;
+    }
+    return done;
+  };
+  auto debug_line = [&]() {
+    if (!getenv("GENEO_DEBUG")) return;
+    fprintf(stderr, "[lobpcg %s] it %d maxres:", P.label, it);
+    for (int s = 0; s < ns; ++s) {
+      double mx = 0.0;
+      for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
+      fprintf(stderr, " %.2e", mx);
+    }
+    fprintf(stderr, " | locked");
+    for (int s = 0; s < ns; ++s) {
+      int nl = 0;
+      for (int j = 0; j < m; ++j) nl += locked[(size_t)s * m + j] ? 1 : 0;
+      fprintf(stderr, " %d", nl);
+    }
+    fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
+  };
   for (it = 0; it <= opt.eps_max_it; ++it) {
     // the A X / B X blocks are carried by recurrence (A S C); refresh them explicitly every few
     // iterations so that rounding drift (eps * ||A|| ||x|| per update, large for high-contrast
@@ -1226,58 +1305,18 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     double* W = S + 2 * m;
     // one pass: residual block (columns locked in EARLIER iterations come out zero) + the three norms
     bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, have_mask ? dmask : nullptr, dn3);
-    bk::d2h(n3.data(), dn3, sizeof(double) * (size_t)ns * 3 * m);
-    for (int s = 0; s < ns; ++s)
-      for (int j = 0; j < m; ++j) {
-        nr[(size_t)s * m + j] = n3[(size_t)s * 3 * m + j];
-        na[(size_t)s * m + j] = n3[(size_t)s * 3 * m + m + j];
-        nb[(size_t)s * m + j] = n3[(size_t)s * 3 * m + 2 * m + j];
-      }
-    all_done = true;
-    for (int s = 0; s < ns; ++s) {
-      if (frozen[s]) continue;
-      bool sub_done = true;
-      for (int j = 0; j < m; ++j) {
-        const size_t e = (size_t)s * m + j;
-        const double den = std::sqrt(na[e]) + std::fabs(lam[e]) * std::sqrt(nb[e]);
-        res[s][j] = den > 0 ? std::sqrt(nr[e]) / den : 0.0;
-        // soft locking: a converged pair stays in X (and in the Rayleigh-Ritz) but no longer
-        // contributes search directions -- its W / P columns would only inject rounding noise
-        static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
-        if (lam[e] >= 1e299 || (res[s][j] <= tol && !nolock)) locked[e] = 1;
-        if (nolock && j < nev_s[s] && res[s][j] > tol) sub_done = false;
-        if (j < nev_s[s] && !locked[e]) sub_done = false;
-      }
-      if (sub_done) frozen[s] = 1;
-      else all_done = false;
-    }
-    if (getenv("GENEO_DEBUG")) {
-      fprintf(stderr, "[lobpcg %s] it %d maxres:", P.label, it);
-      for (int s = 0; s < ns; ++s) {
-        double mx = 0.0;
-        for (int j = 0; j < nev_s[s]; ++j) mx = std::max(mx, res[s][j]);
-        fprintf(stderr, " %.2e", mx);
-      }
-      fprintf(stderr, " | locked");
-      for (int s = 0; s < ns; ++s) {
-        int nl = 0;
-        for (int j = 0; j < m; ++j) nl += locked[(size_t)s * m + j] ? 1 : 0;
-        fprintf(stderr, " %d", nl);
-      }
-      fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
-    }
-    if (all_done || it == opt.eps_max_it) break;
-    // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
-    // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
-    bool changed = false;
-    for (size_t e = 0; e < locked.size(); ++e) {
-      const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-      if (mk != mask[e]) changed = true;
-      mask[e] = mk;
-    }
-    if (changed) {
-      bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
-      have_mask = true;
+    if (!conv_sinvert) {
+      bk::d2h(n3.data(), dn3, sizeof(double) * (size_t)ns * 3 * m);
+      for (int s = 0; s < ns; ++s)
+        for (int j = 0; j < m; ++j) {
+          const size_t e = (size_t)s * m + j;
+          const double nrj = n3[(size_t)s * 3 * m + j], naj = n3[(size_t)s * 3 * m + m + j], nbj = n3[(size_t)s * 3 * m + 2 * m + j];
+          const double den = std::sqrt(naj) + std::fabs(lam[e]) * std::sqrt(nbj);
+          res[s][j] = den > 0 ? std::sqrt(nrj) / den : 0.0;
+        }
+      all_done = update_locks();
+      debug_line();
+      if (all_done || it == opt.eps_max_it) break;
     }
     if (P.amg) {
       // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
@@ -1299,6 +1338,32 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     applyA(W, AS + 2 * m);
     applyB(W, BS + 2 * m);
+    gram_blocks(p3);
+    if (conv_sinvert) {
+      // || T r_j ||_B / || x_j ||_B off the diagonal of S^T B S (columns masked earlier have W_j = 0: they stay locked)
+      for (int s = 0; s < ns; ++s)
+        for (int j = 0; j < m; ++j) {
+          const double* gb = hGB.data() + (size_t)s * p3 * p3;
+          const double ww = gb[(size_t)(2 * m + j) * p3 + 2 * m + j], xx = gb[(size_t)j * p3 + j];
+          res[s][j] = (xx > 0.0 && ww > 0.0) ? std::sqrt(ww / xx) : 0.0;
+        }
+      all_done = update_locks();
+      debug_line();
+      if (all_done || it == opt.eps_max_it) break;
+    }
+    // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
+    // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
+    bool changed = false;
+    for (size_t e = 0; e < locked.size(); ++e) {
+      const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+      if (mk != mask[e]) changed = true;
+      mask[e] = mk;
+    }
+    if (changed) {
+      bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
+      have_mask = true;
+    }
+    lam_prev = lam;
     rayleigh_ritz(p3, m, 2 * m, true);
   }
   info.eig_iterations += it;
@@ -1422,6 +1487,7 @@ int PC::eigen_lobpcg() {
     std::vector<const HostCsr*> dm(ns);
     for (int s = 0; s < ns; ++s) dm[s] = &subs[s].a_dir;
     dirB = upload_blockdiag(dm, suboff, nullptr);
+    dirB.fine = true;
     own_dirB = true;
   }
   double *Xt = nullptr, *Xg = nullptr;

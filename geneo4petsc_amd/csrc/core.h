@@ -33,6 +33,7 @@ struct Options {
   int eps_nev = 16;        // block target when -geneo_cut is not given (no inertia count on the GPU)
   int eps_max_it = 500;
   int eps_block = 0;       // LOBPCG block size m (0 = auto: multiple of 16 >= nev + guard)
+  std::string eps_conv = "sinvert";   // convergence test: ARPACK's shift-invert Ritz estimate | plain "residual" (core.cpp)
   int cheb_degree = 6;     // Chebyshev-Jacobi preconditioner inside LOBPCG
   double cheb_ratio = 20.0;
   double rr_drop = 1e-6;   // pivot threshold of the rank-revealing Rayleigh-Ritz (basis conditioning <= 1/drop)

@@ -142,6 +142,26 @@ PetscErrorCode PCGenEOSetComm(GENEO_PC pc, int rank, int size, int n_owned, cons
  * exchange instead of one.  Default width 1. */
 PetscErrorCode PCGenEOSetCommWidth(GENEO_PC pc, int max_width);
 
+/* C++ transport over RCCL / xGMI built into the library (csrc/comm_rccl.cpp): the counterpart of the reference's
+ * VecScatter (src/geneo.cpp:156,:1850,:1881) and MPI reductions (:1474) for one process per GPU.  Halo exchanges are
+ * ncclSend / ncclRecv groups with the neighbours, reductions ncclAllReduce, all on the stream given to GeneoSetStream.
+ * Bootstrap: rank 0 calls GeneoRcclUniqueId and the HOST broadcasts the 128 bytes (MPI_Bcast, torch.distributed, ...);
+ * every rank then calls GeneoRcclCreate (collective) and attaches its PCs with PCGenEOSetCommRccl, which allocates the
+ * device buffers (max_width vectors per exchange, cf. PCGenEOSetCommWidth) and installs the two callbacks of
+ * PCGenEOSetComm.  RCCL is resolved with dlopen: no link-time dependency. */
+typedef struct _p_GeneoRccl* GeneoRccl;
+PetscErrorCode GeneoRcclUniqueId(char* id128);
+PetscErrorCode GeneoRcclCreate(const char* id128, int rank, int size, GeneoRccl* comm);
+PetscErrorCode PCGenEOSetCommRccl(GENEO_PC pc, GeneoRccl comm, int n_owned, const int* owned_gid, int n_halo,
+                                  const int* halo_gid, const int* recv_counts, const int* send_counts,
+                                  const int* send_idx, int max_width);
+PetscErrorCode GeneoRcclDestroy(GeneoRccl* comm);
+const char* GeneoRcclGetError(void);
+/* bring-up hooks: the device buffers of the which-th attached plan and direct calls of its two callbacks */
+PetscErrorCode GeneoRcclPlanBuffers(GeneoRccl comm, int which, double** send_dev, double** recv_dev, double** red_dev);
+PetscErrorCode GeneoRcclPlanExchange(GeneoRccl comm, int which, int flag);
+PetscErrorCode GeneoRcclPlanAllreduce(GeneoRccl comm, int which, int n);
+
 /* ---- PC operations (the PETSc ops table, src/geneo.cpp:2717-2720) ------------------------- */
 PetscErrorCode PCSetUp_GenEO(GENEO_PC pc);                                   /* setUpGenEOPC :1672 */
 PetscErrorCode PCApply_GenEO(GENEO_PC pc, const double* x_dev, double* y_dev); /* applyGenEOPC :2051 */
@@ -220,9 +240,20 @@ PetscErrorCode GeneoSpmvDestroy(GeneoSpmv* h);
  * HIP events on the launch stream; stop returns the summed kernel ms and algorithmic bytes. */
 PetscErrorCode GeneoSpmvProfileStart(int every, double min_bytes);  /* launches moving < min_bytes are skipped */
 PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
+/* the same for every hot kernel class at once: 0 fine-level CSR SpMV, 1 fine-level SpMM (16 / 32 / 64 columns),
+ * 2 MFMA Gram (S^T T), 3 MFMA block update (S C).  Start ... the library's work ... Stop, then Get per class: summed
+ * kernel ms, algorithmic bytes and flops of the SAMPLED launches, their number and the number of launches seen. */
+PetscErrorCode GeneoKernelProfileStart(int every, double spmv_min_bytes);
+PetscErrorCode GeneoKernelProfileStop(void);
+PetscErrorCode GeneoKernelProfileGet(int kernel_class, double* ms_sum, double* bytes_sum, double* flops_sum,
+                                     long long* nsampled, long long* nlaunch);
 /* Y = post.*(A (pre.*X)), row-major n x m blocks */
 PetscErrorCode GeneoSpmmApply(GeneoSpmv h, const double* X_dev, double* Y_dev, int m, const double* pre_dev,
                               const double* post_dev);
+/* the same on strided blocks (leading dimensions ldx / ldy >= m), timed: average kernel time of `reps` back-to-back
+ * launches, HIP events on the library stream (reps <= 0: one untimed launch, ms_avg untouched) */
+PetscErrorCode GeneoSpmmTime(GeneoSpmv h, const double* X_dev, int ldx, double* Y_dev, int ldy, int m,
+                             const double* pre_dev, const double* post_dev, int reps, double* ms_avg);
 /* multigrid epilogues fused into the SpMV (m = 1) / SpMM launch, row-major n x m blocks:
  *   epi 1: Y = B - A X      2: Y = Z + A X      3: Y = X + w dinv.*(B - A X)      4: Z = w dinv.*B, Y = B - A Z */
 PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, int m, const double* B_dev,

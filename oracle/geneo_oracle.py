@@ -192,6 +192,7 @@ class GenEOOracle:
         self.E = None
         self.x0 = None
         self.dense_limit = 1500
+        self.exact_eigs = False   # pencils above dense_limit: ARPACK at -els2_eps_tol (the reference's call) | certified exact
 
     # -- operators -------------------------------------------------------------------
     def matmult(self, x: np.ndarray) -> np.ndarray:
@@ -281,6 +282,8 @@ class GenEOOracle:
                 order = np.argsort(-np.abs(w), kind="stable")
             order = order[:min(nev, n)]
             return w[order], v[:, order]
+        if self.exact_eigs and pb == "tau":
+            return self._eigen_solve_complete(a, b, nev)
         kw = {}
         if self.o.eps_max_it > 0:
             kw["maxiter"] = self.o.eps_max_it * n
@@ -292,6 +295,32 @@ class GenEOOracle:
             w, v = spla.eigsh(a.tocsc(), k=nev, M=b.tocsc(), which="LM", tol=tol, ncv=ncv, **kw)
             order = np.argsort(-np.abs(w), kind="stable")
         return w[order], v[:, order]
+
+    def _eigen_solve_complete(self, a, b, nev):
+        """The nev lowest eigenpairs of a pencil too large for LAPACK, to machine precision AND provably complete:
+        ARPACK shift-invert (the solver SLEPc drives for the reference, geneo.cpp:649-663) run with tol = 0 and a
+        guard of extra pairs, then Sylvester's law of inertia on A - s B (the reference's own device, geneo.cpp:452-500)
+        with a shift s inside a gap above the wanted ones: the number of negative pivots must equal the number of
+        computed values below s, else a copy of a multiplet was missed and the guard is widened."""
+        n = a.shape[0]
+        k = min(n - 2, nev + 12)
+        ac, bc = a.tocsc(), b.tocsc()
+        while True:
+            w, v = spla.eigsh(ac, k=k, M=bc, sigma=0.0, which="LM", tol=0, ncv=min(n - 1, max(3 * k, 60)))
+            order = np.argsort(np.abs(w), kind="stable")
+            w, v = w[order], v[:, order]
+            below = None
+            for j in range(len(w) - 1, nev - 1, -1):        # a shift inside a relative gap of at least 1e-6
+                if w[j] - w[j - 1] > 1e-6 * abs(w[j]):
+                    shift, below = 0.5 * (w[j] + w[j - 1]), j
+                    break
+            if below is not None:
+                neg, _null, _pos = _inertia_negative_count((a - shift * b).tocsr())
+                if neg == below:
+                    return w[:nev], v[:, :nev]
+            if k >= n - 2:
+                raise RuntimeError("oracle: could not certify the lowest %d eigenvalues" % nev)
+            k = min(n - 2, k + 16)
 
     def _eigen_local_problem(self, p, a, b, param, pb, vals, vecs):
         """eigenLocalProblem, geneo.cpp:842-963."""

@@ -1,4 +1,6 @@
 """Shared test-case builders (product host code for the inputs, oracle for the expected values)."""
+import os
+
 import numpy as np
 
 from geneo4petsc_amd import decomp
@@ -18,7 +20,19 @@ def oracle_for(mesh, dec, argv, b):
     subs = [go.Subdomain(d.l2g, d.a_neu, d.mult, d.intersect) for d in dec.domains]
     orc = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv))
     orc.dense_limit = 4000      # LAPACK ground truth for every test-sized pencil (ARPACK misses multiplets)
+    orc.exact_eigs = True       # above that: ARPACK to machine precision + inertia proof that no copy is missing
     return orc.setup(b)
+
+
+BENCH_OVERLAP = 2
+
+
+def bench_argv(extra=()):
+    """bench.py's own option set (bench.py::geneo_argv with its defaults; tests/test_bench_options.py keeps the two
+    in step)."""
+    return ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.35", "-geneo_cut", "20", "-els2_eps_tol", "0.001",
+            "-ksp_type", "cg", "-ksp_rtol", "1e-05", "-dls1_ksp_rtol", "1e-06", "-dls1_pc_type", "amg",
+            "-els2_pc_type", "amg"] + list(extra)
 
 
 def ksp_args(argv):
@@ -59,8 +73,11 @@ def graph_case(size=400, level=2, nb=4, overlap=1, no_ground=True):
     return mesh, dec, a, decomp.rhs_default(a)
 
 
+COUNT_DRIFT = []     # (case, library count, oracle count) of every declared / recorded iteration-count difference
+
+
 def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, xtol=1e-8, aptol=1e-9, case=None,
-                        dim=3, with_intersect=False):
+                        dim=3, with_intersect=False, count_drift=None):
     """Full parity check of one configuration: integer outputs exact, floats within tolerance."""
     if case is not None:
         mesh, dec, a, b = case
@@ -74,17 +91,21 @@ def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, x
     info = pc.info()
     assert pc.name == orc.o.name
     assert reason == res.reason, (reason, res.reason)
-    # Iteration count: identical to the oracle's.  One documented exception:
-    # Krylov recurrences in finite precision (PETSc's CG, and GMRES with unrefined classical
-    # Gram-Schmidt) turn chaotic once the first Ritz values have converged -- the oracle's OWN count
-    # moves by +-1 when b is perturbed by 1e-14 (tests/test_oracle_eig.py::
-    # test_cg_count_is_rounding_sensitive), most visibly on symmetric cubes whose spectra have exact
-    # multiplicities.  When the counts differ the bar is therefore: same operator (checked below to
-    # 1e-9), same first 8 residual norms to 1e-8, and a count within +-2.
+    # Iteration count: identical to the oracle's -- always for GMRES, and for CG unless the case is DECLARED
+    # rounding-sensitive by its test (count_drift=(library count, oracle count), justified there).  Every use of
+    # such a declaration is recorded in COUNT_DRIFT and printed in the terminal summary (tests/conftest.py), so a
+    # run shows which cases took it; an undeclared difference fails.  GENEO_TEST_COUNT_DRIFT=record turns the
+    # failure into a record (discovery runs on a new device only).
     if its != res.its:
-        assert abs(its - res.its) <= 2, "iteration count differs: %d vs oracle %d" % (its, res.its)
+        label = "%s n=%s parts=%s overlap=%s %s" % (lib.GeneoBackendName().decode(), n, parts, overlap, " ".join(argv))
+        COUNT_DRIFT.append((label, its, res.its))
         k = min(8, len(res.history), len(pc.residual_history()))
         np.testing.assert_allclose(pc.residual_history()[:k], res.history[:k], rtol=1e-8)
+        if os.environ.get("GENEO_TEST_COUNT_DRIFT") != "record":
+            assert ksp == "cg", "GMRES iteration count differs: %d vs oracle %d" % (its, res.its)
+            assert count_drift is not None, "undeclared CG iteration-count difference: %d vs oracle %d" % (its, res.its)
+            assert (its, res.its) in count_drift, "CG count %d vs oracle %d is not the declared drift %r" % (
+                its, res.its, count_drift)
     if orc.o.lvl2:
         assert list(pc.local_dims()) == orc.realDimELoc                                  # integer selection
         assert info["nicolaidesLoc"] == sum(orc.nicolaidesLoc)

@@ -10,3 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Every iteration-count difference against the oracle that a test declared (or a discovery run recorded)."""
+    try:
+        import cases
+    except Exception:
+        return
+    if cases.COUNT_DRIFT:
+        terminalreporter.write_sep("-", "iteration-count differences against the oracle (declared cases)")
+        for label, its, ref in cases.COUNT_DRIFT:
+            terminalreporter.write_line("  %d vs oracle %d : %s" % (its, ref, label))
+    else:
+        terminalreporter.write_line("iteration counts: every compared case identical to the oracle's")

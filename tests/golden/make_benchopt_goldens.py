@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/benchopt.json: the oracle's results at bench.py's OWN option set
+(-geneo_lvl SRAS,1, overlap 2, -geneo_cut 20, tau 0.35, -els2_eps_tol 1e-3, PCG rtol 1e-5) on grids too large to
+re-run the oracle inside the GPU test budget.  The oracle's eigenpairs are the certified-exact ones
+(oracle/geneo_oracle.py::_eigen_solve_complete: ARPACK shift-invert to machine precision + Sylvester inertia proof of
+completeness) and its local solves are exact LU: this is the limit the reference's MUMPS / ARPACK path tends to.
+
+    python tests/golden/make_benchopt_goldens.py 32 48 64        (minutes; run once, commit the JSON)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases                                  # noqa: E402
+from oracle import geneo_oracle as go         # noqa: E402
+
+OUT = os.path.join(HERE, "benchopt.json")
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [32, 48]
+    data = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for n in sizes:
+        t0 = time.time()
+        argv = cases.bench_argv()
+        mesh, dec, a, b = cases.grid_case(n=n, dim=3, parts=(2, 2, 2), overlap=cases.BENCH_OVERLAP)
+        orc = cases.oracle_for(mesh, dec, argv, b)
+        ksp, kw = cases.ksp_args(argv)
+        res = go.solve(orc, b, ksp, **kw)
+        data[str(n)] = {
+            "argv": argv, "overlap": cases.BENCH_OVERLAP, "parts": [2, 2, 2], "n": n, "its": int(res.its),
+            "reason": res.reason, "dimE": int(orc.dimE), "realDimELoc": [int(v) for v in orc.realDimELoc],
+            "nicolaides": int(sum(orc.nicolaidesLoc)), "history": [float(v) for v in res.history],
+            "eigvals": [[float(v) for v in np.sort(e)] for e in orc.eigvals],
+            "x_norm": float(np.linalg.norm(res.x)), "x_head": [float(v) for v in res.x[:8]],
+            "oracle_seconds": time.time() - t0}
+        print(n, "its", res.its, "dimE", orc.dimE, "%.0f s" % (time.time() - t0), flush=True)
+        json.dump(data, open(OUT, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

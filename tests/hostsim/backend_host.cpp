@@ -106,6 +106,11 @@ void spmv(const Csr& a, const double* x, double* y) {
   }
 }
 void spmv_profile_start(int, double) {}
+void kernel_profile_start(int, double) {}
+void kernel_profile_stop() {}
+void kernel_profile_get(int, double* a, double* b, double* c, long long* d, long long* e) {
+  if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; if (d) *d = 0; if (e) *e = 0;
+}
 bool spmv_profiling() { return false; }
 void spmv_profile_stop(double* a, double* b, long long* c, long long* d) {
   if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; if (d) *d = 0;
@@ -486,5 +491,6 @@ int selftest_mfma_f64() { return 0; }
 void* event_create() { return nullptr; }
 void event_record(void*) {}
 float event_elapsed_ms(void*, void*) { return 0.f; }
+void event_destroy(void*) {}
 
 }  // namespace bk

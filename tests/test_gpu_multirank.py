@@ -37,7 +37,8 @@ def test_two_ranks_on_one_gpu_match_serial_oracle(tmp_path, lvl, ksp, parts, ext
     kspname, kw = cases.ksp_args(argv)
     res = go.solve(orc, b, kspname, **kw)
     assert meta["dims"] == orc.realDimELoc and meta["dimE"] == orc.dimE
-    assert meta["reason"] == res.reason and abs(meta["its"] - res.its) <= 2
+    assert meta["reason"] == res.reason
+    assert meta["its"] == res.its, (meta["its"], res.its)      # identical, CG included (no tolerance on the count)
     np.testing.assert_allclose(got["m"], orc.matmult(b), rtol=1e-12, atol=1e-9)
     assert np.linalg.norm(got["y"] - orc.apply(b)) <= 1e-9 * np.linalg.norm(orc.apply(b))
     assert np.linalg.norm(got["x"] - res.x) <= 1e-7 * np.linalg.norm(res.x)
