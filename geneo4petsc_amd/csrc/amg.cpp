@@ -366,6 +366,7 @@ AmgDevice::~AmgDevice() { free_all(); }
 
 void AmgDevice::free_all() {
   for (auto& L : lv) {
+    bk::csr_free(L.Acs);
     if (L.own_A) bk::csr_free(L.A);
     bk::csr_free(L.P);
     bk::csr_free(L.R);
@@ -405,6 +406,7 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
     bk::h2d(L.dinv, H.dinv.data(), sizeof(double) * L.n);
     alloc_level_buffers(L, l > 0);
     L.fused = bk::csr_fusable(L.A) && (l + 1 == (int)levels.size() || bk::csr_fusable(L.P)) && !getenv("GENEO_AMG_UNFUSED");
+    if (l + 1 < levels.size()) make_column_scaled(L);
     if (l == 0) nnz0 = (double)H.nnz;
     nnzt += (double)H.nnz;
     lv.push_back(L);
@@ -416,6 +418,12 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
   bk::h2d(d_inv, coarse_inv.data(), sizeof(double) * coarse_inv.size());
   d_invbase = (int64_t*)bk::alloc(sizeof(int64_t) * coarse_base.size());
   bk::h2d(d_invbase, coarse_base.data(), sizeof(int64_t) * coarse_base.size());
+}
+
+void AmgDevice::make_column_scaled(Lvl& L) {
+  // only the sliced kernels know about pre-scaled values; ragged levels keep the explicit scaling
+  if (L.fused && L.A.vec_lpr == 0 && L.A.nlong == 0 && L.A.n > 0 && !getenv("GENEO_AMG_NO_PRESCALE"))
+    L.Acs = bk::csr_scaled_alias(L.A, nullptr, L.dinv, true);
 }
 
 void AmgDevice::alloc_level_buffers(Lvl& L, bool coarse) {
@@ -529,6 +537,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     L.R = R;
     alloc_level_buffers(L, l > 0);
     L.fused = bk::csr_fusable(L.A) && bk::csr_fusable(L.P) && !getenv("GENEO_AMG_UNFUSED");
+    make_column_scaled(L);
     lv.push_back(L);
     // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse
     HostCsr next;
@@ -596,7 +605,7 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
     // damped-Jacobi V-cycle in 4 launches per level: the vector passes ride on the SpMV / SpMM epilogues
     const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
     const double w = 1.0 / (0.5 * (lmax + lmin));
-    bk::spmm_fused(L.A, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
+    bk::spmm_fused(L.Acs.n ? L.Acs : L.A, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
     applyA(L.R, L.r, m, C0.b, m, m);                                                      // restrict
     cycle(l + 1, C0.b, m, C0.x, m, m);
     bk::spmm_fused(L.P, bk::EPI_ADD, C0.x, m, L.d, m, m, nullptr, 0, X, ldx, nullptr, 0.0);  // t = x + P e

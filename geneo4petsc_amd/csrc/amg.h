@@ -58,6 +58,7 @@ class AmgDevice {
  private:
   struct Lvl {
     bk::Csr A, P, R;
+    bk::Csr Acs;              // A diag(dinv), values only: the zero-guess sweep (EPI_PRE) then gathers b alone
     double* dinv = nullptr;
     double *b = nullptr, *x = nullptr, *r = nullptr, *d = nullptr, *ad = nullptr;  // n x max_m work blocks
     int n = 0;
@@ -73,6 +74,7 @@ class AmgDevice {
   int maxm = 1;
   double opc = 1.0;
   void alloc_level_buffers(Lvl& L, bool coarse);
+  void make_column_scaled(Lvl& L);
   void applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m);
   void smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int m, bool zero_guess);
   void cycle(int l, const double* B, int ldb, double* X, int ldx, int m);

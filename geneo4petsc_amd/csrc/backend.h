@@ -53,6 +53,8 @@ struct Csr {
   // grid walks the schedule entries xcd_ptr[g] .. xcd_ptr[g + 1]
   int* sched = nullptr;        // nslice
   int* xcd_ptr = nullptr;      // 9
+  bool alias = false;          // values-only copy of another matrix (csr_scaled_alias): the index arrays are borrowed
+  bool col_scaled = false;     // the values already carry the column scaling the EPI_PRE epilogue would apply (A diag(dinv))
   bool fine = false;           // a subdomain-level (fine) operator: its launches are the ones bench.py's in-situ timer samples
   int vec_lpr = 0;             // > 0: long / ragged rows (restriction, coarse Galerkin operators): the SpMV runs the
                                // lanes-per-row CSR kernel with this many lanes per row instead of the slices
@@ -74,6 +76,10 @@ void csr_finish(Csr& a);
 void csr_download(const Csr& a, int* rowptr, int* col, double* val);   // host arrays sized n+1 / nnz / nnz
 // same matrix with every column index c replaced by map_dev[c] (device-side copy: no host round trip)
 Csr  csr_remap_columns(const Csr& a, const int* map_dev);
+// diag(row_scale) A diag(col_scale) as a values-only copy: rowptr / col / layouts are BORROWED from `a` (which must
+// outlive the copy); either scaling may be null.  col_is_dinv marks A diag(dinv) for the EPI_PRE epilogue, which then
+// skips its own column scaling (one gather less per entry).
+Csr  csr_scaled_alias(const Csr& a, const double* row_scale, const double* col_scale, bool col_is_dinv);
 void spmv(const Csr& a, const double* x, double* y);                    // y = A x
 // In-situ timing of the SpMV launches issued between start and stop: every `every`-th launch is
 // bracketed by two HIP events on the backend stream (no host sync until stop).

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
 }
 
 int spmv_kind();
-static void finish_layout(Csr& a, const int* h_rowptr);
+static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col = nullptr);
 
 Csr csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
@@ -271,12 +271,78 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
   h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
-  finish_layout(a, h_rowptr);
+  finish_layout(a, h_rowptr, h_col);
   return a;
 }
 // SpMV layouts (LDS row blocks, 64-row slices, long-row list, lanes-per-row choice) of a matrix whose CSR arrays are
 // in HBM; h_rowptr = host copy of the row pointers
-static void finish_layout(Csr& a, const int* h_rowptr) {
+// Slice schedule of the sliced SpMM for matrices whose far neighbours lie further apart than the slices one XCD group
+// holds in flight (a 3-D grid in natural order: the +-z neighbours are a whole plane away -- 186^2 rows = 8.9 MB of a
+// 32-column block, against the 4 MiB L2 of an XCD).  The slices are re-ordered into compact blobs of the slice graph
+// (breadth-first growth from the lowest unvisited slice, TILE slices per blob): the waves of a group then work side by
+// side on one blob, so that a row of X fetched for one slice is still in the group's L2 when the neighbouring slices of
+// the same blob ask for it; only the blob's surface is fetched twice.  Adjacency is sampled (4 rows per slice): the
+// schedule is a traversal order, not part of the result.  Returns an empty vector when the natural order already keeps
+// the neighbours within reach.
+static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_col, int nslice) {
+  constexpr int TILE = 512;
+  static const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto)
+  if (mode && !strcmp(mode, "natural")) return {};
+  if (nslice < 4 * TILE) return {};
+  std::vector<int> adj_ptr((size_t)nslice + 1, 0), adj;
+  adj.reserve((size_t)nslice * 8);
+  int far = 0;
+  for (int s = 0; s < nslice; ++s) {
+    int loc[64];
+    int cnt = 0;
+    const int r0 = 64 * s, r1 = std::min(n, r0 + 64);
+    const int probe[4] = {r0, r0 + 21, r0 + 42, r1 - 1};
+    for (int t = 0; t < 4; ++t) {
+      const int r = std::min(probe[t], r1 - 1);
+      for (int k = h_rowptr[r]; k < h_rowptr[r + 1] && cnt < 60; ++k) {
+        const int o = h_col[k] >> 6;
+        if (o == s || o >= nslice) continue;
+        bool seen = false;
+        for (int i = 0; i < cnt; ++i) seen = seen || loc[i] == o;
+        if (!seen) loc[cnt++] = o;
+      }
+    }
+    for (int i = 0; i < cnt; ++i) {
+      adj.push_back(loc[i]);
+      far = std::max(far, std::abs(loc[i] - s));
+    }
+    adj_ptr[s + 1] = (int)adj.size();
+  }
+  // natural order keeps the far neighbours in flight while they are within a fraction of the slices a group holds
+  if (!(mode && !strcmp(mode, "blob")) && far < TILE / 4) return {};
+  std::vector<int> order;
+  order.reserve(nslice);
+  std::vector<char> seen((size_t)nslice, 0);
+  std::vector<int> queue;
+  int next_seed = 0;
+  while ((int)order.size() < nslice) {
+    while (next_seed < nslice && seen[next_seed]) ++next_seed;
+    if (next_seed >= nslice) break;
+    queue.clear();
+    queue.push_back(next_seed);
+    seen[next_seed] = 1;
+    size_t head = 0;
+    int taken = 0;
+    while (head < queue.size() && taken < TILE) {
+      const int s = queue[head++];
+      order.push_back(s);
+      ++taken;
+      for (int k = adj_ptr[s]; k < adj_ptr[s + 1]; ++k) {
+        const int o = adj[k];
+        if (!seen[o]) { seen[o] = 1; queue.push_back(o); }
+      }
+    }
+    for (; head < queue.size(); ++head) seen[queue[head]] = 0;   // discovered but not taken: back to the pool
+  }
+  return order;
+}
+
+static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
   const int n = a.n;
   int maxrow = 0;
   std::vector<int> longr;
@@ -335,6 +401,13 @@ static void finish_layout(Csr& a, const int* h_rowptr) {
       for (int g = 0; g <= 8; ++g) xp[g] = (int)(((int64_t)ns * g) / 8);
       a.xcd_ptr = (int*)alloc(sizeof(int) * 9);
       h2d(a.xcd_ptr, xp, sizeof(int) * 9);
+      if (h_col && longr.empty()) {
+        const std::vector<int> order = blob_schedule(n, h_rowptr, h_col, ns);
+        if ((int)order.size() == ns) {
+          a.sched = (int*)alloc(sizeof(int) * (size_t)ns);
+          h2d(a.sched, order.data(), sizeof(int) * (size_t)ns);
+        }
+      }
     }
     a.nlong = (int)longr.size();
     // Long or ragged rows (restriction operators, coarse Galerkin matrices): one lane group per row reads the
@@ -633,10 +706,48 @@ void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, do
 }
 
 void csr_free(Csr& a) {
+  if (a.alias) {   // values-only copy: the index arrays belong to the matrix it was made from
+    dfree(a.val); dfree(a.sl_val);
+    a = Csr();
+    return;
+  }
   dfree(a.rowptr); dfree(a.col); dfree(a.val); dfree(a.rowblk);
   dfree(a.sl_ptr); dfree(a.sl_col); dfree(a.sl_val); dfree(a.long_rows);
   dfree(a.sched); dfree(a.xcd_ptr);
   a = Csr();
+}
+
+__global__ void k_scale_csr(int n, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                            const double* __restrict__ rs, const double* __restrict__ cs, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double a = rs ? rs[r] : 1.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) out[k] = a * val[k] * (cs ? cs[col[k]] : 1.0);
+}
+__global__ __launch_bounds__(256) void k_scale_sell(int n, int ns, const int64_t* __restrict__ sl_ptr,
+                                                    const int* __restrict__ sl_col, const double* __restrict__ sl_val,
+                                                    const double* __restrict__ rs, const double* __restrict__ cs,
+                                                    double* __restrict__ out) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= ns) return;
+  const int l = threadIdx.x & 63;
+  const int r = 64 * s + l;
+  const double a = (rs && r < n) ? rs[r] : 1.0;
+  for (int64_t e = sl_ptr[s] + l; e < sl_ptr[s + 1]; e += 64) out[e] = a * sl_val[e] * (cs ? cs[sl_col[e]] : 1.0);
+}
+Csr csr_scaled_alias(const Csr& a, const double* row_scale, const double* col_scale, bool col_is_dinv) {
+  Csr b = a;
+  b.alias = true;
+  b.col_scaled = col_is_dinv;
+  b.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  b.sl_val = (double*)alloc(sizeof(double) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+  if (a.n > 0)
+    hipLaunchKernelGGL(k_scale_csr, dim3(grid1d(a.n, 256)), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, row_scale,
+                       col_scale, b.val);
+  if (a.nslice > 0)
+    hipLaunchKernelGGL(k_scale_sell, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.n, a.nslice, a.sl_ptr, a.sl_col,
+                       a.sl_val, row_scale, col_scale, b.sl_val);
+  return b;
 }
 
 // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs (b % 8 = XCD group).
@@ -733,7 +844,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
                                                        const int* __restrict__ col, const double* __restrict__ val,
                                                        const double* __restrict__ x, double* __restrict__ y,
                                                        const double* __restrict__ b, double* __restrict__ z,
-                                                       const double* __restrict__ dinv, double w) {
+                                                       const double* __restrict__ dinv, double w,
+                                                       const double* __restrict__ cs /* EPI_PRE: column scaling, null when the values carry it */) {
   constexpr int UNR = 4;
   const int nwb = (nslice + 3) >> 2;
   const int t = xcd_remap(blockIdx.x, nwb);
@@ -754,12 +866,12 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
       v[u] = NT ? __builtin_nontemporal_load(val + e + 64 * u) : val[e + 64 * u];
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) acc[u] += v[u] * (EPI == EPI_PRE ? b[c[u]] * dinv[c[u]] : x[c[u]]);
+    for (int u = 0; u < UNR; ++u) acc[u] += v[u] * (EPI == EPI_PRE ? (cs ? b[c[u]] * cs[c[u]] : b[c[u]]) : x[c[u]]);
   }
   for (; e < e1; e += 64) {
     const int c0 = NT ? __builtin_nontemporal_load(col + e) : col[e];
     const double v0 = NT ? __builtin_nontemporal_load(val + e) : val[e];
-    acc[0] += v0 * (EPI == EPI_PRE ? b[c0] * dinv[c0] : x[c0]);
+    acc[0] += v0 * (EPI == EPI_PRE ? (cs ? b[c0] * cs[c0] : b[c0]) : x[c0]);
   }
   double sum = acc[0];
 #pragma unroll
@@ -1042,13 +1154,35 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
 // 1 KiB per instruction) and the Y store of those rows is one contiguous 1 KiB segment.  The slice's (col, val) entries
 // are read ONCE, coalesced and non-temporal (lane = row of the slice, as the SpMV does), staged in a wave-private LDS
 // tile and handed to the row groups by broadcast reads: no dependent global load in front of the X gathers.
+// The gathers of a step group (U steps x KW entries, e.g. 4 x 7 = 28 KiB per wave) are all issued before the first
+// product: the body is instantiated per entry count KW so that no branch sits between them (the first version had a
+// branch per entry and drained its 4 loads each time: 0.35 ms; see DESIGN.md section 7 for the history).
 //
 // Traversal: persistent grid; the hardware deals workgroups round-robin over the 8 XCDs, workgroup b belongs to XCD
 // group b & 7 and that group walks ITS OWN contiguous range of the slice schedule (xptr[g] .. xptr[g + 1]) with all its
 // waves side by side.  The rows of X a group touches at any time are the few hundred slices its waves hold plus their
 // neighbours: that window, not the whole block, is what the XCD's private 4 MiB L2 has to keep.  (Which XCD a group
 // lands on does not matter for correctness.)  sched == nullptr: slices in natural order.
-template <int LG, int EPI>
+typedef double spmm_d2 __attribute__((ext_vector_type(2)));
+template <int LG, int U, int KW>
+__device__ __forceinline__ void spmm_sell_accum(const int* mc, const double* mv, int rl0, const double* __restrict__ Xq,
+                                                int ldx, spmm_d2* acc) {
+  constexpr int RS = 64 / LG;
+  spmm_d2 x[KW][U];
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = mc[k * 64 + rl0 + u * RS];
+      x[k][u] = *reinterpret_cast<const spmm_d2*>(Xq + (int64_t)c * ldx);
+    }
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] += mv[k * 64 + rl0 + u * RS] * x[k][u];
+}
+
+template <int LG, int EPI, int U>
 __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
                                                    const double* __restrict__ sl_val, int n,
                                                    const int* __restrict__ sched, const int* __restrict__ xptr,
@@ -1056,11 +1190,11 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
                                                    const double* __restrict__ pre, const double* __restrict__ post,
                                                    const double* __restrict__ B, int ldb, double* __restrict__ Z, int ldz,
                                                    const double* __restrict__ dinv, double w) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef spmm_d2 d2;
   constexpr int KC = 8;              // entries per row staged per chunk
   constexpr int RS = 64 / LG;        // rows per wave-wide load
   constexpr int NSTEP = 64 / RS;     // steps per slice
-  constexpr int U = (NSTEP < 4) ? NSTEP : 4;   // steps in flight
+  static_assert(NSTEP % U == 0, "steps in flight must divide the steps of a slice");
   __shared__ int lc[4][KC * 64];
   __shared__ double lv[4][KC * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1068,6 +1202,7 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
   const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
   int* mc = lc[wave];
   double* mv = lv[wave];
+  const double* Xq = X + 2 * q;
   for (int it = xptr[xg] + slot * 4 + wave; it < xptr[xg + 1]; it += wpx * 4) {
     const int s = sched ? sched[it] : it;
     const int64_t base = sl_ptr[s];
@@ -1093,18 +1228,17 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-          if (k < kc) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int rl = (g * U + u) * RS + grp;
-              const int c = mc[k * 64 + rl];
-              const double v = mv[k * 64 + rl];
-              const d2 x = *reinterpret_cast<const d2*>(X + (int64_t)c * ldx + 2 * q);
-              acc[u] += v * x;
-            }
-          }
+        const int rl0 = g * U * RS + grp;
+        switch (kc) {                         // wave-uniform
+          case 8: spmm_sell_accum<LG, U, 8>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 7: spmm_sell_accum<LG, U, 7>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 6: spmm_sell_accum<LG, U, 6>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 5: spmm_sell_accum<LG, U, 5>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 4: spmm_sell_accum<LG, U, 4>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 3: spmm_sell_accum<LG, U, 3>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 2: spmm_sell_accum<LG, U, 2>(mc, mv, rl0, Xq, ldx, acc); break;
+          case 1: spmm_sell_accum<LG, U, 1>(mc, mv, rl0, Xq, ldx, acc); break;
+          default: break;
         }
       }
 #pragma unroll
@@ -1135,6 +1269,7 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
 }
 
 static int g_spmm_wpx = -1;      // workgroups per XCD group of the sliced SpMM (GENEO_SPMM_WPX; 0 = old CSR kernel)
+static int g_spmm_u = 2;         // steps in flight per wave (GENEO_SPMM_U: 1, 2 or 4)
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // true when the launch was taken by the sliced kernel
 template <int EPI>
@@ -1143,6 +1278,8 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
                              double w) {
   if (g_spmm_wpx < 0) {
     const char* e = getenv("GENEO_SPMM_WPX");
+    const char* u = getenv("GENEO_SPMM_U");
+    if (u) g_spmm_u = atoi(u);
     g_spmm_wpx = e ? atoi(e) : 128;   // measured at 126^3 (0.35 ms): 64 -> 0.43, 192 -> 0.39, 256 -> 0.41 ms
   }
   if (g_spmm_wpx == 0 || spmv_kind() != 1 || a.vec_lpr > 0 || a.nlong > 0 || !a.sl_ptr || !a.xcd_ptr) return false;
@@ -1153,12 +1290,19 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
   int wpx = g_spmm_wpx;
   const int need = (a.nslice + 31) / 32;
   if (wpx > need) wpx = need < 1 ? 1 : need;
-#define SELLMM(L)                                                                                                    \
-  hipLaunchKernelGGL((k_spmm_sell<L, EPI>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
+#define SELLMM2(L, UU)                                                                                                  \
+  hipLaunchKernelGGL((k_spmm_sell<L, EPI, UU>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
                      a.sched, a.xcd_ptr, X, ldx, Y, ldy, pre, post, B, ldb, Z, ldz, dinv, w)
+#define SELLMM(L)                  \
+  do {                             \
+    if (g_spmm_u >= 4) SELLMM2(L, 4); \
+    else if (g_spmm_u == 2) SELLMM2(L, 2); \
+    else SELLMM2(L, 1);            \
+  } while (0)
   if (m == 16) SELLMM(8);
   else if (m == 32) SELLMM(16);
   else SELLMM(32);
+#undef SELLMM2
 #undef SELLMM
   return true;
 }
@@ -1205,12 +1349,12 @@ static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int 
     // (126^3) the non-temporal hint changes nothing for them (50.7 / 40.2 us vs 49.5 / 39.4 us), while the lines
     // they leave in the Infinity Cache are what the next plain SpMV of the same matrix hits (38.5 vs 48.0 us).
     hipLaunchKernelGGL((k_spmv_sell_epi<false, EPI>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
-                       a.n, a.sl_col, a.sl_val, X, Y, B, Z, dinv, w);
+                       a.n, a.sl_col, a.sl_val, X, Y, B, Z, dinv, w, a.col_scaled ? (const double*)nullptr : dinv);
     return;
   }
   const double* Xin = (EPI == EPI_PRE) ? B : X;
   const int ldin = (EPI == EPI_PRE) ? ldb : ldx;
-  const double* pre = (EPI == EPI_PRE) ? dinv : nullptr;
+  const double* pre = (EPI == EPI_PRE && !a.col_scaled) ? dinv : nullptr;
   // + the epilogue's block reads / writes: RES, ADD one more block in, JAC two, PRE one more out
   ProfScope prof(PROF_SPMM, a.fine && m >= 16,
                  (double)a.nnz * 12.0 + (double)a.n * 4.0 + (16.0 + (EPI == EPI_JAC ? 16.0 : 8.0)) * m * (double)a.n,

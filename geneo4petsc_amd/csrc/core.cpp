@@ -1126,7 +1126,12 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   double *dGA = dv((size_t)ns * p3 * p3), *dGB = dv((size_t)ns * p3 * p3), *dC = dv((size_t)ns * p3 * 2 * m);
   double *dlam = dv((size_t)ns * m), *dnr = dv((size_t)ns * m), *dna = dv((size_t)ns * m), *dnb = dv((size_t)ns * m);
   std::vector<double*> owned_bufs = {S, AS, BS, T, AT, BT, cr, cd, cad, dGA, dGB, dC, dlam, dnr, dna, dnb};
-  auto cleanup = [&]() { for (double* p : owned_bufs) bk::dfree(p); };
+  void** graphs_to_free = nullptr;
+  auto cleanup = [&]() {
+    for (double* p : owned_bufs) bk::dfree(p);
+    if (graphs_to_free)
+      for (int i = 0; i < 2; ++i) bk::graph_destroy(graphs_to_free[i]);
+  };
 
   auto applyA = [&](const double* X, double* Y) { bk::spmm_strided(*P.A, X, p3, Y, p3, m, P.As, P.As); info.eig_spmm++; };
   auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(*P.B, X, p3, Y, p3, m, P.Bs, P.Bs); info.eig_spmm++; };
@@ -1144,10 +1149,14 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   std::vector<double> mask((size_t)ns * m, 1.0);
   double* dmask = dv((size_t)ns * m);
   owned_bufs.push_back(dmask);
+  bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());   // all ones: the device phase always takes the mask
+  void* it_graph[2] = {nullptr, nullptr};                       // HIP graphs of the device phase, one per buffer parity
+  bool it_graph_failed = false;
+  static const bool no_graph = getenv("GENEO_LOBPCG_NO_GRAPH") != nullptr;
+  graphs_to_free = it_graph;
   double* dn3 = dv((size_t)ns * 3 * m);
   owned_bufs.push_back(dn3);
   std::vector<double> n3((size_t)ns * 3 * m);
-  bool have_mask = false;
   double t_rr_host = 0.0, t_dev_wait = 0.0;
   auto t_lob0 = clk::now();
   // Gram blocks of the leading p columns, symmetrised on the host
@@ -1236,6 +1245,13 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   for (int s = 0; s < ns; ++s) nev_s[s] = std::min(nev_try, (int)subs[s].l2g.size());
   static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
   std::vector<double> lam_prev((size_t)ns * m, 1e300);   // Ritz values of the previous iteration (straggler test)
+  // A pair is ACCEPTED at the tolerance but keeps iterating (its W / P columns stay in the basis) until it is far below
+  // it: the reference's ARPACK stops when the slowest wanted pair meets tol, by which time the others are orders of
+  // magnitude better; locking every pair AT tol would leave the whole coarse space at the tolerance's worst case (64^3,
+  // tol 1e-3: Ritz values 2e-3 off inside the dense cluster, outer PCG 26 instead of 24 iterations).  The lock proper
+  // (columns dropped: at tight tolerances they would only inject rounding noise) comes at max(tol^2, min(tol, 1e-10)).
+  const double tol_lock = std::max(tol * tol, std::min(tol, 1e-10));
+  std::vector<char> conv((size_t)ns * m, 0);
   // locks + frozen subdomains from res[][]; returns true when every subdomain is done
   auto update_locks = [&]() {
     bool done = true;
@@ -1246,9 +1262,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         const size_t e = (size_t)s * m + j;
         // soft locking: a converged pair stays in X (and in the Rayleigh-Ritz) but no longer
         // contributes search directions -- its W / P columns would only inject rounding noise
-        if (lam[e] >= 1e299 || (res[s][j] <= tol && !nolock)) locked[e] = 1;
-        if (nolock && j < nev_s[s] && res[s][j] > tol) sub_done = false;
-        if (j < nev_s[s] && !locked[e]) sub_done = false;
+        if (lam[e] >= 1e299 || (res[s][j] <= tol_lock && !nolock)) locked[e] = 1;
+        if (lam[e] >= 1e299 || res[s][j] <= tol) conv[e] = 1;      // sticky: a pair that met the tolerance stays accepted
+        if (j < nev_s[s] && !conv[e]) sub_done = false;
       }
       // No straggler: a Ritz pair behind the wanted ones that has not converged may still be on its way to an
       // eigenvalue BELOW the last wanted one (a late copy of a multiplet: symmetric subdomains have 3- and 6-fold
@@ -1263,7 +1279,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         const double last = lam[(size_t)s * m + nev_s[s] - 1] * (1.0 + tol);
         for (int j = nev_s[s]; j < m; ++j) {
           const size_t e = (size_t)s * m + j;
-          if (locked[e] || lam[e] >= 1e299) continue;
+          if (conv[e] || lam[e] >= 1e299) continue;
           const double drop = (lam_prev[e] < 1e299) ? std::max(0.0, lam_prev[e] - lam[e]) : lam[e];
           if (lam[e] / (1.0 + res[s][j]) > last) continue;
           if (lam[e] - 12.0 * drop > last) continue;
@@ -1303,9 +1319,41 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     // residual into the W slot, convergence test
     bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
     double* W = S + 2 * m;
-    // one pass: residual block (columns locked in EARLIER iterations come out zero) + the three norms
-    bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, have_mask ? dmask : nullptr, dn3);
+    // The device part of one iteration -- residual, preconditioner, A W, B W, the two Gram blocks: ~45 launches, many of
+    // them on the small coarse levels of the V-cycle where the host cannot issue as fast as the GPU retires.  With the
+    // shift-invert test nothing in it needs the host, so it is captured once per buffer parity (S / T swap roles every
+    // iteration) into a HIP graph and replayed.
+    auto precondition = [&]() {
+      if (P.amg) {
+        // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
+        P.amg->vcycle(cr, m, W, p3, m);
+        info.eig_spmm += 3;
+      } else {
+        // W = T r : Chebyshev iteration on A z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
+        double rho = 1.0 / sigma;
+        bk::block_rowscale(cd, m, cr, m, P.dinv, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
+        bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                      // z = d
+        for (int k = 1; k < opt.cheb_degree; ++k) {
+          bk::spmm_strided(*P.A, cd, m, cad, m, m, P.As, P.As);              // A d
+          info.eig_spmm++;
+          const double rho_new = 1.0 / (2.0 * sigma - rho);
+          // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
+          bk::cheb_update(cr, cad, cd, W, p3, P.dinv, 2.0 * rho_new / delta, rho_new * rho, nL, m);
+          rho = rho_new;
+        }
+      }
+    };
+    auto device_phase = [&]() {
+      // one pass: residual block (columns locked in EARLIER iterations come out zero) + the three norms
+      bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, dn3);
+      precondition();
+      applyA(W, AS + 2 * m);
+      applyB(W, BS + 2 * m);
+      bk::gram(ch, S, p3, p3, AS, p3, p3, dGA);
+      bk::gram(ch, S, p3, p3, BS, p3, p3, dGB);
+    };
     if (!conv_sinvert) {
+      bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, dn3);
       bk::d2h(n3.data(), dn3, sizeof(double) * (size_t)ns * 3 * m);
       for (int s = 0; s < ns; ++s)
         for (int j = 0; j < m; ++j) {
@@ -1317,28 +1365,40 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       all_done = update_locks();
       debug_line();
       if (all_done || it == opt.eps_max_it) break;
-    }
-    if (P.amg) {
-      // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
-      P.amg->vcycle(cr, m, W, p3, m);
-      info.eig_spmm += 3;
+      precondition();
+      applyA(W, AS + 2 * m);
+      applyB(W, BS + 2 * m);
+      gram_blocks(p3);
     } else {
-      // W = T r : Chebyshev iteration on A z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
-      double rho = 1.0 / sigma;
-      bk::block_rowscale(cd, m, cr, m, P.dinv, 1.0 / theta, 0.0, nL, m);  // d = Dinv r / theta
-      bk::block_axpby(W, p3, 1.0, cd, m, 0.0, nL, m);                      // z = d
-      for (int k = 1; k < opt.cheb_degree; ++k) {
-        bk::spmm_strided(*P.A, cd, m, cad, m, m, P.As, P.As);              // A d
-        info.eig_spmm++;
-        const double rho_new = 1.0 / (2.0 * sigma - rho);
-        // r -= A d ; d = (2 rho'/delta) Dinv r + rho' rho d ; z += d   (one fused pass)
-        bk::cheb_update(cr, cad, cd, W, p3, P.dinv, 2.0 * rho_new / delta, rho_new * rho, nL, m);
-        rho = rho_new;
+      // it 0 runs direct (first calls size scratch buffers); while bench.py's in-situ kernel timer is on every 8th
+      // iteration runs direct so that its launches can be bracketed by events (graph nodes cannot)
+      const int par = it & 1;
+      const bool direct = no_graph || it == 0 || (bk::spmv_profiling() && it % 8 == 0);
+      if (!direct && !it_graph[par] && !it_graph_failed) {
+        const int spmm_before = info.eig_spmm;
+        if (bk::graph_capture_begin()) {
+          try {
+            device_phase();
+          } catch (...) {
+            bk::graph_capture_end();
+            throw;
+          }
+          it_graph[par] = bk::graph_capture_end();
+        }
+        info.eig_spmm = spmm_before;   // recorded, not run
+        if (!it_graph[par]) it_graph_failed = true;
       }
+      if (!direct && it_graph[par]) {
+        bk::graph_launch(it_graph[par]);
+        info.eig_spmm += P.amg ? 5 : 2 + opt.cheb_degree - 1;   // what device_phase counts when it runs direct
+      } else {
+        device_phase();
+      }
+      auto tg0 = clk::now();
+      bk::d2h(hGA.data(), dGA, sizeof(double) * (size_t)ns * p3 * p3);
+      bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p3 * p3);
+      t_dev_wait += secs(tg0, clk::now());
     }
-    applyA(W, AS + 2 * m);
-    applyB(W, BS + 2 * m);
-    gram_blocks(p3);
     if (conv_sinvert) {
       // || T r_j ||_B / || x_j ||_B off the diagonal of S^T B S (columns masked earlier have W_j = 0: they stay locked)
       for (int s = 0; s < ns; ++s)
@@ -1359,10 +1419,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       if (mk != mask[e]) changed = true;
       mask[e] = mk;
     }
-    if (changed) {
-      bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
-      have_mask = true;
-    }
+    if (changed) bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
     lam_prev = lam;
     rayleigh_ritz(p3, m, 2 * m, true);
   }
@@ -1490,10 +1547,14 @@ int PC::eigen_lobpcg() {
     dirB.fine = true;
     own_dirB = true;
   }
+  // B = D A_Dir D (geneo.cpp:1243-1247, MatDiagonalScale on a copy) as a values-only copy sharing A_Dir's index
+  // arrays: the block products with B then run without the two scaling gathers per entry
+  bk::Csr dirBD = bk::csr_scaled_alias(dirB, d_D, d_D, false);
   double *Xt = nullptr, *Xg = nullptr;
   auto release = [&]() {
     if (Xt) bk::dfree(Xt);
     if (Xg) bk::dfree(Xg);
+    bk::csr_free(dirBD);
     if (own_dirB) bk::csr_free(dirB);
   };
   info.eig_iterations = 0;
@@ -1543,7 +1604,7 @@ int PC::eigen_lobpcg() {
   };
   int m_t = m, m_g = m, nev_t = nev_try, nev_g = nev_try;
   {
-    EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirB, g2 ? nullptr : d_D, (opt.els2_pc == "amg") ? amgN : nullptr,
+    EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirBD, nullptr, (opt.els2_pc == "amg") ? amgN : nullptr,
                   d_dinvN, cheb_lmax, nev_try, "tau"};
     if (opt.check)
       if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release(); return rc; }
@@ -1552,7 +1613,7 @@ int PC::eigen_lobpcg() {
   if (g2) {
     if (int rc = local_gamma()) { release(); return rc; }
     if (int rc = finish_amg1()) { release(); return rc; }   // the gamma problem runs through the level-1 hierarchy
-    EigProblem pg{&dirL, nullptr, &dirB, d_D, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
+    EigProblem pg{&dirL, nullptr, &dirBD, nullptr, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
                   d_dinv1, cheb_lmax1, nev_try, "gamma"};
     if (opt.check) {  // the reference checks the B of the gamma pencil as given to SLEPc: A_Rob (geneo.cpp:1299,:884)
       EigProblem pchk = pg;

@@ -26,8 +26,8 @@
  *     decomposition.
  *   - not re-entrant; one context per PC; collective over the ranks given to PCGenEOSetComm.
  */
-#ifndef __GENEO_C_H
-#define __GENEO_C_H
+#ifndef __GENEOPC_C_ABI_H
+#define __GENEOPC_C_ABI_H   /* not the reference guard (__GENEO_C_H): the PETSc-side adapter includes both headers */
 
 #include <stddef.h>
 #include <stdint.h>

@@ -30,10 +30,16 @@ def main():
     doms = [decomp.decompose_grid_domain(n, 3, (split,) * 3, 2, s) for s in range(nb)]
     a = sp.block_diag([d.a_dir for d in doms], format="csr")
     rows = a.shape[0]
+    # ceiling experiments (MATRIX=diag | tri | planes): the same launch on a matrix that keeps only some of the 7 gathers
+    kind = os.environ.get("MATRIX", "")
+    if kind:
+        offs = {"diag": [0], "tri": [-1, 0, 1], "planes": [-(n // split + 4) ** 2, 0, (n // split + 4) ** 2],
+                "lines": [-(n // split + 4), -1, 0, 1, (n // split + 4)]}[kind]
+        a = sp.diags([np.full(rows - abs(o), 1.0 + 0.1 * i) for i, o in enumerate(offs)], offs, format="csr")
     h = Spmv(a, lib)
     by = a.nnz * 12 + rows * (4 + 16 * m)
     out = {"n": n, "subdomains": nb, "rows": rows, "nnz": int(a.nnz), "m": m, "algorithmic_bytes": by,
-           "wpx": os.environ.get("GENEO_SPMM_WPX", "default")}
+           "wpx": os.environ.get("GENEO_SPMM_WPX", "default"), "matrix": os.environ.get("MATRIX", "A_Dir")}
     rng = np.random.default_rng(1)
     for ld in (m, 3 * m):
         Xh = rng.random((rows, ld))

@@ -16,14 +16,38 @@ def grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1, **gen):
     return mesh, dec, a, b
 
 
-def oracle_for(mesh, dec, argv, b):
+def oracle_for(mesh, dec, argv, b, literal=False):
+    """literal=False: eigenpairs exact (the limit -els2_eps_tol -> 0).  literal=True: the reference's own call, ARPACK
+    shift-invert AT -els2_eps_tol (geneo.cpp:649-663) -- the oracle of the parity tests at the bench option set, where
+    the tolerance is the reference's default 1e-3 and the quality of the deflation depends on it."""
     subs = [go.Subdomain(d.l2g, d.a_neu, d.mult, d.intersect) for d in dec.domains]
     orc = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv))
-    orc.dense_limit = 4000      # LAPACK ground truth for every test-sized pencil (ARPACK misses multiplets)
-    orc.exact_eigs = True       # above that: ARPACK to machine precision + inertia proof that no copy is missing
+    if literal:
+        orc.dense_limit, orc.exact_eigs = 0, False
+    else:
+        orc.dense_limit = 4000      # LAPACK ground truth for every test-sized pencil (ARPACK misses multiplets)
+        orc.exact_eigs = True       # above that: ARPACK to machine precision + inertia proof that no copy is missing
     return orc.setup(b)
 
 
+class Tight:
+    """`argv + TIGHT`: the tolerances of the mode-parity tests, chosen by the Krylov method already in argv.
+    Eigenpairs converged to 1e-10 (the limit in which the coarse space is unique).  Krylov tolerance 1e-8 for GMRES;
+    1e-6 for CG: PCG amplifies the rounding-level difference between ANY two implementations of the same
+    preconditioner (exact LU here, PCG to 1e-12 there; or two different summation orders) about tenfold per iteration
+    once its first Ritz values have converged -- 1e-11 at iteration 12, 1e-6 at 17, O(1) near 25 on the 12^3 cases
+    (tests/test_oracle_eig.py::test_cg_count_is_rounding_sensitive shows it on the oracle alone).  Counts are compared
+    where the two runs are still the same computation, and there they must be IDENTICAL: no tolerance on the count."""
+
+    def __radd__(self, argv):
+        ksp = "gmres"
+        for i, a in enumerate(argv):
+            if a == "-ksp_type":
+                ksp = argv[i + 1]
+        return list(argv) + ["-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-6" if ksp == "cg" else "1e-8"]
+
+
+TIGHT = Tight()
 BENCH_OVERLAP = 2
 
 
@@ -31,7 +55,7 @@ def bench_argv(extra=()):
     """bench.py's own option set (bench.py::geneo_argv with its defaults; tests/test_bench_options.py keeps the two
     in step)."""
     return ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.35", "-geneo_cut", "20", "-els2_eps_tol", "0.001",
-            "-ksp_type", "cg", "-ksp_rtol", "1e-05", "-dls1_ksp_rtol", "1e-06", "-dls1_pc_type", "amg",
+            "-ksp_type", "cg", "-ksp_rtol", "1e-05", "-dls1_ksp_rtol", "1e-08", "-dls1_pc_type", "amg",
             "-els2_pc_type", "amg"] + list(extra)
 
 

@@ -44,7 +44,7 @@ def main():
         comm = TorchComm(plan, "cpu")
     pc = GenEOPC(lib)
     pc.set_from_options(["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp,
-                         "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"] + extra)
+                         "-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-6" if ksp == "cg" else "1e-8"] + extra)
     pc.set_sizes(n ** 3, nb)
     comm.attach(pc)
     for d in doms:

@@ -97,7 +97,19 @@ void csr_download(const Csr& a, int* rowptr, int* col, double* val) {
   memcpy(col, a.col, sizeof(int) * a.nnz);
   memcpy(val, a.val, sizeof(double) * a.nnz);
 }
-void csr_free(Csr& a) { dfree(a.rowptr); dfree(a.col); dfree(a.val); a = Csr(); }
+void csr_free(Csr& a) {
+  if (a.alias) { dfree(a.val); a = Csr(); return; }
+  dfree(a.rowptr); dfree(a.col); dfree(a.val); a = Csr();
+}
+Csr csr_scaled_alias(const Csr& a, const double* rs, const double* cs, bool col_is_dinv) {
+  Csr b = a;
+  b.alias = true;
+  b.col_scaled = col_is_dinv;
+  b.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  for (int r = 0; r < a.n; ++r)
+    for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) b.val[k] = (rs ? rs[r] : 1.0) * a.val[k] * (cs ? cs[a.col[k]] : 1.0);
+  return b;
+}
 void spmv(const Csr& a, const double* x, double* y) {
   for (int i = 0; i < a.n; ++i) {
     double s = 0;
@@ -141,7 +153,7 @@ void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int 
       double s = 0;
       for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
         const int c = a.col[k];
-        s += a.val[k] * (epi == EPI_PRE ? dinv[c] * B[(int64_t)c * ldb + j] : X[(int64_t)c * ldx + j]);
+        s += a.val[k] * (epi == EPI_PRE ? (a.col_scaled ? 1.0 : dinv[c]) * B[(int64_t)c * ldb + j] : X[(int64_t)c * ldx + j]);
       }
       double& y = Y[(int64_t)i * ldy + j];
       if (epi == EPI_RES) y = B[(int64_t)i * ldb + j] - s;

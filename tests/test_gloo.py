@@ -32,7 +32,7 @@ def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     mesh, dec, a, b = cases.grid_case(12, 3, parts, 1)
     np.testing.assert_allclose(got["b"], b, rtol=1e-13)
     argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp, "-els2_eps_tol", "1e-10",
-            "-ksp_rtol", "1e-8"] + extra
+            "-ksp_rtol", "1e-6" if ksp == "cg" else "1e-8"] + extra     # cases.Tight: CG counts at 1e-6
     orc = cases.oracle_for(mesh, dec, argv, b)
     kspname, kw = cases.ksp_args(argv)
     res = go.solve(orc, b, kspname, **kw)

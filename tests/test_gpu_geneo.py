@@ -12,7 +12,7 @@ import dummy_cases as dc
 
 pytestmark = pytest.mark.gpu
 
-TIGHT = ["-els2_eps_tol", "1e-10", "-ksp_rtol", "1e-8"]
+TIGHT = cases.TIGHT      # eigenpairs 1e-10; Krylov 1e-8 (GMRES) / 1e-6 (CG): see cases.Tight
 
 
 @pytest.fixture(scope="module")
