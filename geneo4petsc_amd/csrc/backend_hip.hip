@@ -1936,14 +1936,20 @@ __global__ __launch_bounds__(256) void k_gram_fma(const int* __restrict__ cstart
 }
 
 // sum the partial Grams of each subdomain in fixed order
-__global__ void k_gram_reduce(const int* __restrict__ gsubptr, const double* __restrict__ Gpart, int pq,
-                              double* __restrict__ G) {
+// 64 output entries per workgroup, 4 thread sets: set k sums the partial matrices g = first + k, first + k + 4, ... in
+// order, the four sums are combined in fixed order -- four independent load streams instead of one dependent chain
+__global__ __launch_bounds__(256) void k_gram_reduce(const int* __restrict__ gsubptr, const double* __restrict__ Gpart,
+                                                     int pq, double* __restrict__ G) {
+  __shared__ double sm[4][64];
   const int s = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= pq) return;
+  const int el = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   double acc = 0.0;
-  for (int g = gsubptr[s]; g < gsubptr[s + 1]; ++g) acc += Gpart[(int64_t)g * pq + e];
-  G[(int64_t)s * pq + e] = acc;
+  if (e < pq)
+    for (int g = gsubptr[s] + k; g < gsubptr[s + 1]; g += 4) acc += Gpart[(int64_t)g * pq + e];
+  sm[k][el] = acc;
+  __syncthreads();
+  if (k == 0 && e < pq) G[(int64_t)s * pq + e] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
 }
 
 // host-side cache of the gram grouping for a Chunks object (keyed by its device pointer)
@@ -2037,7 +2043,7 @@ void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, in
     hipLaunchKernelGGL(k_gram_fma, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, pl.gcount,
                        S, lds_, p, T, ldt_, q, pl.part);
   }
-  hipLaunchKernelGGL(k_gram_reduce, dim3(grid1d(p * q, 256), c.nsub), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
+  hipLaunchKernelGGL(k_gram_reduce, dim3(grid1d(p * q, 64), c.nsub), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
                      p * q, G);
 }
 
@@ -2178,14 +2184,30 @@ void block_mul(const Chunks& c, const double* S, int lds_, int p, const double* 
 }
 
 // per-chunk column sums -> per-subdomain column sums (fixed order)
-__global__ void k_colsum_reduce(const int* __restrict__ subptr, const double* __restrict__ part, int m,
-                                double* __restrict__ out) {
+// per-chunk column sums -> per-subdomain column sums: K thread sets per column (chunks c = first + k, + K, ... in
+// order), combined in fixed order -- K independent load streams instead of one dependent chain per column
+__global__ __launch_bounds__(1024) void k_colsum_reduce(const int* __restrict__ subptr, const double* __restrict__ part, int m,
+                                                        int w, double* __restrict__ out) {
+  extern __shared__ double smc[];            // K x w
   const int s = blockIdx.x;
-  const int j = threadIdx.x;
-  if (j >= m) return;
+  const int K = blockDim.x / w;
+  const int j = threadIdx.x % w, k = threadIdx.x / w;
   double t = 0.0;
-  for (int c = subptr[s]; c < subptr[s + 1]; ++c) t += part[(int64_t)c * m + j];
-  out[(int64_t)s * m + j] = t;
+  if (j < m)
+    for (int c = subptr[s] + k; c < subptr[s + 1]; c += K) t += part[(int64_t)c * m + j];
+  smc[k * w + j] = t;
+  __syncthreads();
+  if (k == 0 && j < m) {
+    double a = smc[j];
+    for (int i = 1; i < K; ++i) a += smc[i * w + j];
+    out[(int64_t)s * m + j] = a;
+  }
+}
+static void launch_colsum_reduce(const Chunks& c, const double* part, int m, double* out) {
+  const int w = ((m + 15) / 16) * 16;
+  const int K = std::max(1, std::min(8, 1024 / w));
+  if (w > 1024) throw std::runtime_error("colsum_reduce: more than 1024 columns");
+  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(K * w), sizeof(double) * K * w, g_stream, c.subptr, part, m, w, out);
 }
 static double* g_colpart = nullptr;
 static size_t g_colpart_n = 0;
@@ -2235,7 +2257,7 @@ void block_residual(const Chunks& c, const double* AX, int lda, const double* BX
   double* part = colpart((size_t)c.nchunk * m);
   hipLaunchKernelGGL(k_block_residual, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, AX, lda, BX,
                      ldb, lam, m, R, ldr, part);
-  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((m + 63) / 64) * 64), 0, g_stream, c.subptr, part, m, nrm);
+  launch_colsum_reduce(c, part, m, nrm);
 }
 __global__ __launch_bounds__(256) void k_block_residual_norms(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                               const int* __restrict__ csub, const double* __restrict__ AX,
@@ -2282,8 +2304,7 @@ void block_residual_norms(const Chunks& c, const double* AX, int lda, const doub
   double* part = colpart((size_t)c.nchunk * 3 * m);
   hipLaunchKernelGGL(k_block_residual_norms, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, AX, lda,
                      BX, ldb, lam, m, R, ldr, colmask, part);
-  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((3 * m + 63) / 64) * 64), 0, g_stream, c.subptr, part, 3 * m,
-                     nrm3);
+  if (nrm3) launch_colsum_reduce(c, part, 3 * m, nrm3);   // null: the caller only wants the residual block
 }
 __global__ __launch_bounds__(256) void k_block_colnorm(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                        const double* __restrict__ X, int ldx, int m,
@@ -2313,7 +2334,7 @@ void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm
   if (m > 256) throw std::runtime_error("block_colnorm: m > 256");
   double* part = colpart((size_t)c.nchunk * m);
   hipLaunchKernelGGL(k_block_colnorm, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, X, ldx, m, part);
-  hipLaunchKernelGGL(k_colsum_reduce, dim3(c.nsub), dim3(((m + 63) / 64) * 64), 0, g_stream, c.subptr, part, m, nrm);
+  launch_colsum_reduce(c, part, m, nrm);
 }
 
 // strided elementwise: Y[i][j] = a*X[i][j] + b*Y[i][j]   (b == 0 => pure assignment, Y not read)

@@ -159,6 +159,7 @@ class PC {
   int finish_amg1();
   void* cg_graph = nullptr;    // HIP graph of one inner-PCG chunk (local_solve)
   bool cg_graph_failed = false;
+  long long cg_chunks = 0;     // chunks issued so far (sampling of direct launches while the in-situ timer runs)
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 

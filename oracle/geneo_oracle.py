@@ -284,7 +284,9 @@ class GenEOOracle:
             return w[order], v[:, order]
         if self.exact_eigs and pb == "tau":
             return self._eigen_solve_complete(a, b, nev)
-        kw = {}
+        # fixed start vector: ARPACK's own random start continues one Fortran RNG stream across calls, so the same
+        # pencil would give different bases depending on what ran before (SLEPc seeds its EPS start vector once)
+        kw = {"v0": np.random.default_rng(20181).random(n) + 0.5}
         if self.o.eps_max_it > 0:
             kw["maxiter"] = self.o.eps_max_it * n
         ncv = min(n - 1, max(2 * nev + 1, 20))

@@ -149,6 +149,10 @@ def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, x
     assert np.linalg.norm(m1 - m2) <= 1e-13 * np.linalg.norm(m2)
     # same iterate when the counts agree; otherwise two different iterates of the same convergent sequence,
     # each within the Krylov tolerance of the solution
-    assert np.linalg.norm(x - res.x) <= (xtol if its == res.its else 5 * xtol) * np.linalg.norm(res.x)
+    # (PCG: the two iterates carry the amplified rounding difference described in Tight -- up to 1e-7 after ~20
+    # iterations on the GPU, whose summation orders differ from numpy's: bar = the Krylov tolerance 1e-6 itself)
+    rel = np.linalg.norm(x - res.x) / np.linalg.norm(res.x)
+    bar = (xtol if its == res.its else 5 * xtol) * (100.0 if ksp == "cg" else 1.0)
+    assert rel <= bar, "iterate differs from the oracle's by %.2e (bar %.1e)" % (rel, bar)
     pc.destroy()
     return its, info

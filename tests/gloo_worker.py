@@ -26,7 +26,7 @@ def main():
     from geneo4petsc_amd.comm import TorchComm, gather_owned
     from geneo4petsc_amd.pc import GenEOPC
     n, ov = 12, 1
-    nb = 8
+    nb = parts[0] * parts[1] * parts[2]      # 8 in the mode tests; 2 = one subdomain per rank (the bench's N > 1 layout)
     sub_rank = np.arange(nb) * size // nb
     doms = [decomp.decompose_grid_domain(n, 3, parts, ov, s) for s in range(nb) if sub_rank[s] == rank]
     plan = decomp.grid_rank_plan(n, 3, parts, ov, sub_rank, rank, size, doms)

@@ -389,9 +389,11 @@ void block_residual_norms(const Chunks& c, const double* AX, int lda, const doub
         R[(int64_t)i * ldr + j] = mk * v;
         tr += v * v; ta += a * a; tb += b * b;
       }
-      nrm3[(int64_t)s * 3 * m + j] = tr;
-      nrm3[(int64_t)s * 3 * m + m + j] = ta;
-      nrm3[(int64_t)s * 3 * m + 2 * m + j] = tb;
+      if (nrm3) {
+        nrm3[(int64_t)s * 3 * m + j] = tr;
+        nrm3[(int64_t)s * 3 * m + m + j] = ta;
+        nrm3[(int64_t)s * 3 * m + 2 * m + j] = tb;
+      }
     }
 }
 void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm) {

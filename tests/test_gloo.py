@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("lvl,ksp,parts,extra", [
     ("ASM,1", "cg", (2, 2, 2), []), ("RAS,H1", "gmres", (2, 2, 2), []),
+    ("SRAS,1", "cg", (2, 1, 1), []),        # ONE subdomain per rank: the layout of bench.py --gpus N (config 3)
     ("SORAS,2", "cg", (4, 2, 1), ["-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", "12", "-geneo_optim", "0.5"])])
 def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     out = str(tmp_path / "res.npz")
