@@ -192,6 +192,7 @@ class GenEOOracle:
         self.E = None
         self.x0 = None
         self.dense_limit = 1500
+        self.arpack_seed = 20181  # start vector of the literal-mode ARPACK runs (see _eigen_solve)
         self.exact_eigs = False   # pencils above dense_limit: ARPACK at -els2_eps_tol (the reference's call) | certified exact
 
     # -- operators -------------------------------------------------------------------
@@ -286,7 +287,7 @@ class GenEOOracle:
             return self._eigen_solve_complete(a, b, nev)
         # fixed start vector: ARPACK's own random start continues one Fortran RNG stream across calls, so the same
         # pencil would give different bases depending on what ran before (SLEPc seeds its EPS start vector once)
-        kw = {"v0": np.random.default_rng(20181).random(n) + 0.5}
+        kw = {"v0": np.random.default_rng(self.arpack_seed).random(n) + 0.5}
         if self.o.eps_max_it > 0:
             kw["maxiter"] = self.o.eps_max_it * n
         ncv = min(n - 1, max(2 * nev + 1, 20))

@@ -16,7 +16,7 @@ def grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1, **gen):
     return mesh, dec, a, b
 
 
-def oracle_for(mesh, dec, argv, b, literal=False):
+def oracle_for(mesh, dec, argv, b, literal=False, arpack_seed=None):
     """literal=False: eigenpairs exact (the limit -els2_eps_tol -> 0).  literal=True: the reference's own call, ARPACK
     shift-invert AT -els2_eps_tol (geneo.cpp:649-663) -- the oracle of the parity tests at the bench option set, where
     the tolerance is the reference's default 1e-3 and the quality of the deflation depends on it."""
@@ -24,6 +24,8 @@ def oracle_for(mesh, dec, argv, b, literal=False):
     orc = go.GenEOOracle(mesh.nbNode, subs, go.parse_options(argv))
     if literal:
         orc.dense_limit, orc.exact_eigs = 0, False
+        if arpack_seed is not None:
+            orc.arpack_seed = arpack_seed
     else:
         orc.dense_limit = 4000      # LAPACK ground truth for every test-sized pencil (ARPACK misses multiplets)
         orc.exact_eigs = True       # above that: ARPACK to machine precision + inertia proof that no copy is missing

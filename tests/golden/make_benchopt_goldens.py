@@ -9,7 +9,11 @@ re-run the oracle inside the GPU test budget.  Two oracle modes per grid:
                 next to it: at tol 1e-3 the deflation is only as good as the eigenvectors, the outer PCG pays 0-4
                 iterations for it (24^3: 25 against 21), which is the reference's behaviour, not an artefact of the GPU path.
 
-    python tests/golden/make_benchopt_goldens.py [--mode literal|exact_eigs] 32 48 64     (minutes; commit the JSON)
+    python tests/golden/make_benchopt_goldens.py [--mode literal|exact_eigs|seeds] 32 48 64     (minutes; commit the JSON)
+
+  "seeds"       the literal mode again with other ARPACK start vectors (seeds 1-4): at tol 1e-3 ARPACK returns A basis
+                meeting the tolerance, which one depends on where it starts; the spread of the resulting PCG counts is
+                the reference's own indeterminacy at these options ("literal_counts_by_seed").
 """
 import json
 import os
@@ -39,6 +43,17 @@ def main():
         t0 = time.time()
         argv = cases.bench_argv()
         mesh, dec, a, b = cases.grid_case(n=n, dim=3, parts=(2, 2, 2), overlap=cases.BENCH_OVERLAP)
+        if mode == "seeds":
+            ksp, kw = cases.ksp_args(argv)
+            counts = {}
+            for seed in (1, 2, 3, 4):
+                orc = cases.oracle_for(mesh, dec, argv, b, literal=True, arpack_seed=seed)
+                counts[str(seed)] = int(go.solve(orc, b, ksp, **kw).its)
+                print(n, "seed", seed, "its", counts[str(seed)], "%.0f s" % (time.time() - t0), flush=True)
+                data = json.load(open(OUT)) if os.path.exists(OUT) else {}
+                data.setdefault(str(n), {})["literal_counts_by_seed"] = counts
+                json.dump(data, open(OUT, "w"), indent=1)
+            continue
         orc = cases.oracle_for(mesh, dec, argv, b, literal=(mode == "literal"))
         ksp, kw = cases.ksp_args(argv)
         res = go.solve(orc, b, ksp, **kw)
