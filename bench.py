@@ -371,22 +371,25 @@ def main():
         agg_gbs = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
     gbs_rank = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
     if rank == 0:
+        info_rows = sum(len(d.l2g) for d in doms)
         spmv_ws = by_sum.value / max(1, nsamp.value)
         cache_note = ("working set %.0f MB > 256 MiB Infinity Cache: HBM-resident" % (spmv_ws / 1e6)
                       if spmv_ws > 256 * 2 ** 20 else
                       "working set %.0f MB < 256 MiB Infinity Cache: this in-situ rate is cache-assisted, the HBM-resident "
                       "rate of the same kernel and matrix is roofline.spmv_hbm_resident" % (spmv_ws / 1e6))
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE x 2 / WRITE_SIZE, separate passes, as the guide
-        # prescribes; scripts/pmc_report.py, committed under profiles/) -- only quoted when the profiled launch is this one
-        traffic = {}
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x 2 / WRITE_SIZE, separate passes, calibrated in the same
+        # run as the guide prescribes: scripts/pmc.py, committed as profiles/r02_hbm_traffic_pmc.json).  The PMC workload
+        # launches each kernel class on this matrix / these block shapes; the in-situ launches of a class mix variants
+        # (epilogues, widths), so the measured RATIO traffic / algorithmic of the class is applied to the in-situ
+        # algorithmic bytes per launch.
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")))
             for k in kernels:
                 key = k["kernel"].split(" ")[0]
-                if key in prof and abs(prof[key]["algorithmic_bytes"] - k["algorithmic_bytes_per_launch"]) <= \
-                        0.02 * k["algorithmic_bytes_per_launch"]:
-                    k["traffic"] = prof[key]["traffic_bytes_corrected"]
-                    traffic[key] = k["traffic"]
+                hits = [v for name, v in prof.items() if isinstance(v, dict) and name.startswith(key) and "traffic_over_algorithmic" in v]
+                if hits and abs(hits[0].get("rows", info_rows) - info_rows) <= 0.01 * info_rows:
+                    k["traffic_over_algorithmic"] = hits[0]["traffic_over_algorithmic"]
+                    k["traffic"] = hits[0]["traffic_over_algorithmic"] * k["algorithmic_bytes_per_launch"]
         except Exception:
             pass
         dom = max(kernels, key=lambda k: k["share_of_step"]) if kernels else None
@@ -395,7 +398,9 @@ def main():
         if dom is not None:
             roof = {"bound": "hbm", "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-                    "traffic_source": "profiles/r02_hbm_traffic_pmc.json" if dom.get("traffic") else None,
+                    "traffic_source": ("profiles/r02_hbm_traffic_pmc.json: PMC traffic / algorithmic of this kernel class "
+                                       "(%.3f) x the in-situ algorithmic bytes per launch" % dom["traffic_over_algorithmic"])
+                    if dom.get("traffic") else None,
                     "kernel": dom["kernel"], "share_of_step": dom["share_of_step"],
                     "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"],
                     "launches_total": dom["launches_total"],

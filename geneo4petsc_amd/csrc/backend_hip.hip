@@ -147,6 +147,11 @@ void zero(void* d, size_t bytes) {
 }
 
 // ---- HIP graphs: capture on a private stream, replay on the launch stream ----------------------------
+// (the in-situ kernel timer counts what a replay launches: recorded per graph at capture, added at every replay)
+static void graph_counts_reset();
+static void graph_counts_store(void* exec);
+static void graph_counts_add(void* exec);
+static void graph_counts_drop(void* exec);
 static hipStream_t g_capture_stream = nullptr, g_saved_stream = nullptr;
 bool graph_capture_begin() {
   if (g_capturing || getenv("GENEO_NO_GRAPH")) return false;
@@ -159,6 +164,7 @@ bool graph_capture_begin() {
   g_saved_stream = g_stream;
   g_stream = g_capture_stream;
   g_capturing = true;
+  graph_counts_reset();
   return true;
 }
 void* graph_capture_end() {
@@ -171,11 +177,18 @@ void* graph_capture_end() {
   hipGraphExec_t exec = nullptr;
   const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
-  return e2 == hipSuccess ? (void*)exec : nullptr;
+  if (e2 != hipSuccess) return nullptr;
+  graph_counts_store((void*)exec);
+  return (void*)exec;
 }
-void graph_launch(void* exec) { HIPCHK(hipGraphLaunch((hipGraphExec_t)exec, g_stream)); }
+void graph_launch(void* exec) {
+  HIPCHK(hipGraphLaunch((hipGraphExec_t)exec, g_stream));
+  graph_counts_add(exec);
+}
 void graph_destroy(void* exec) {
-  if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+  if (!exec) return;
+  graph_counts_drop(exec);
+  (void)hipGraphExecDestroy((hipGraphExec_t)exec);
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -971,7 +984,8 @@ void set_spmv_kind(int kind) {
 // two HIP events on the launch stream; nothing waits on the host until stop.  Classes (backend.h): fine-level CSR
 // SpMV, fine-level SpMM, MFMA Gram, MFMA block update.
 struct KProf {
-  long long nlaunch = 0;
+  long long nlaunch = 0;     // direct launches seen (every `every`-th of them is timed)
+  long long ngraph = 0;      // launches replayed from HIP graphs (counted, never timed)
   std::vector<hipEvent_t> e0, e1;
   std::vector<double> bytes, flops;
 };
@@ -979,10 +993,14 @@ static bool g_prof_on = false;
 static int g_prof_every = 1;
 static double g_prof_min_bytes = 0.0;
 static KProf g_kprof[PROF_NCLASS];
+static long long g_capture_count[PROF_NCLASS] = {0, 0, 0, 0};
+struct GraphCounts { void* exec; long long n[PROF_NCLASS]; };
+static std::vector<GraphCounts> g_graph_counts;
 struct ProfScope {   // e0 at construction, e1 at destruction, when this launch is one of the sampled ones
   KProf* k = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
   ProfScope(int cls, bool counted, double bytes, double flops) {
+    if (g_capturing && counted) ++g_capture_count[cls];    // what one replay of the graph being recorded will launch
     if (!g_prof_on || g_capturing || !counted) return;
     KProf& kp = g_kprof[cls];
     if (kp.nlaunch++ % g_prof_every != 0 || kp.e0.size() >= 20000) return;
@@ -1005,6 +1023,31 @@ static void kprof_clear(KProf& k) {
   for (hipEvent_t e : k.e1) (void)hipEventDestroy(e);
   k.e0.clear(); k.e1.clear(); k.bytes.clear(); k.flops.clear();
   k.nlaunch = 0;
+  k.ngraph = 0;
+}
+static void graph_counts_reset() {
+  for (long long& v : g_capture_count) v = 0;
+}
+static void graph_counts_store(void* exec) {
+  GraphCounts gc;
+  gc.exec = exec;
+  for (int i = 0; i < PROF_NCLASS; ++i) gc.n[i] = g_capture_count[i];
+  g_graph_counts.push_back(gc);
+}
+static void graph_counts_add(void* exec) {
+  if (!g_prof_on) return;
+  for (const GraphCounts& gc : g_graph_counts)
+    if (gc.exec == exec) {
+      for (int i = 0; i < PROF_NCLASS; ++i) g_kprof[i].ngraph += gc.n[i];
+      return;
+    }
+}
+static void graph_counts_drop(void* exec) {
+  for (size_t i = 0; i < g_graph_counts.size(); ++i)
+    if (g_graph_counts[i].exec == exec) {
+      g_graph_counts.erase(g_graph_counts.begin() + i);
+      return;
+    }
 }
 void kernel_profile_start(int every, double spmv_min_bytes) {
   for (KProf& k : g_kprof) kprof_clear(k);
@@ -1032,7 +1075,7 @@ void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flop
   if (bytes_sum) *bytes_sum = by;
   if (flops_sum) *flops_sum = fl;
   if (nsampled) *nsampled = (long long)k.e1.size();
-  if (nlaunch) *nlaunch = k.nlaunch;
+  if (nlaunch) *nlaunch = k.nlaunch + k.ngraph;
 }
 void spmv_profile_start(int every, double min_bytes) { kernel_profile_start(every, min_bytes); }
 bool spmv_profiling() { return g_prof_on; }

@@ -111,11 +111,11 @@ def report(fd, wd, alg_json):
                 groups = [("_ld32", f_all[:6], w_all[:6]), ("_ld96", f_all[6:], w_all[6:])]
             for suffix, fv, wv in groups:
                 fr, wr = mean(fv) * 1024.0, mean(wv) * 1024.0
-                short = kname.split("(")[0].replace("bk::", "")
+                short = kname.split("(")[0].replace("bk::", "").replace("void ", "").strip()
                 rep[short.split("<")[0] + suffix if suffix else short] = {
                     "kernel": short, "launches": len(fv), "FETCH_SIZE_bytes_raw": fr, "WRITE_SIZE_bytes_raw": wr,
                     "read_bytes_corrected": fr * corr_r, "write_bytes_corrected": wr * corr_w,
-                    "traffic_bytes_corrected": fr * corr_r + wr * corr_w, "algorithmic_bytes": alg[key],
+                    "traffic_bytes_corrected": fr * corr_r + wr * corr_w, "algorithmic_bytes": alg[key], "rows": alg["rows"],
                     "traffic_over_algorithmic": (fr * corr_r + wr * corr_w) / alg[key]}
     print(json.dumps(rep, indent=1))
 
