@@ -65,9 +65,10 @@ def build_parser():
     ap.add_argument("--cut", type=int, default=20)
     ap.add_argument("--eps-tol", type=float, default=1e-3, help="reference default, geneo.cpp:658")
     ap.add_argument("--rtol", type=float, default=1e-5, help="PETSc KSP default rtol")
-    ap.add_argument("--dls1-rtol", type=float, default=1e-8,
-                    help="relative tolerance of the inner (local) solves: 1e-8 leaves the outer PCG at rtol 1e-5 where exact "
-                         "local solves put it (20^3..32^3: 22 / 25 / 24 / 26 iterations = the oracle's; 1e-6 costs 0-2 more)")
+    ap.add_argument("--dls1-rtol", type=float, default=1e-7,
+                    help="relative tolerance of the inner (local) solves: 1e-7 (and 3e-7, 1e-8, 1e-10) leaves the outer PCG at "
+                         "rtol 1e-5 where exact local solves put it (20^3..32^3: 22 / 25 / 24 / 26 iterations = the oracle's); "
+                         "1e-6 costs 1-2 more at 24^3 and 28^3")
     ap.add_argument("--dls1-pc", default="amg", help="inner preconditioner of the local solves: amg | jacobi")
     ap.add_argument("--els2-pc", default="amg", help="LOBPCG preconditioner: amg | cheb")
     ap.add_argument("--pc-args", default="", help="further options for the PC")

@@ -298,7 +298,7 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
 // schedule is a traversal order, not part of the result.  Returns an empty vector when the natural order already keeps
 // the neighbours within reach.
 static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_col, int nslice) {
-  constexpr int TILE = 512;
+  static const int TILE = getenv("GENEO_SPMM_TILE") ? atoi(getenv("GENEO_SPMM_TILE")) : 512;
   static const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto)
   if (mode && !strcmp(mode, "natural")) return {};
   if (nslice < 4 * TILE) return {};
@@ -1323,7 +1323,10 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
     const char* e = getenv("GENEO_SPMM_WPX");
     const char* u = getenv("GENEO_SPMM_U");
     if (u) g_spmm_u = atoi(u);
-    g_spmm_wpx = e ? atoi(e) : 128;   // measured at 126^3 (0.35 ms): 64 -> 0.43, 192 -> 0.39, 256 -> 0.41 ms
+    // 126^3 fine level, time / PMC traffic over algorithmic per (steps in flight U, workgroups per XCD group):
+    // (2, 64) 0.337 ms / 1.13   (1, 128) 0.332 / 1.31   (4, 64) 0.334 / 1.35   (2, 128) 0.356 / 1.58   (4, 128) 0.35 / 1.60:
+    // the time is flat, the over-fetch grows with the gathers a group holds in flight (its L2 window)
+    g_spmm_wpx = e ? atoi(e) : 64;
   }
   if (g_spmm_wpx == 0 || spmv_kind() != 1 || a.vec_lpr > 0 || a.nlong > 0 || !a.sl_ptr || !a.xcd_ptr) return false;
   if (m != 16 && m != 32 && m != 64) return false;
