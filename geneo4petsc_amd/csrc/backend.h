@@ -173,6 +173,14 @@ void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm
 // nrm3[s*3m + j] = ||AX_j - lam_j BX_j||^2 (unmasked), nrm3[s*3m + m + j] = ||AX_j||^2, nrm3[s*3m + 2m + j] = ||BX_j||^2
 void block_residual_norms(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
                           int m, double* R, int ldr, const double* colmask, double* nrm3);
+// Fused Rayleigh-Ritz update of one LOBPCG iteration for m = 32 (S, AS, BS: n x 96 row-major, [X | P | W]):
+//   [X' P'] = S C (C: nsub x 96 x 64 row-major with the structure core.cpp gives it: the P columns equal the X columns on
+//   the P / W rows for kept pairs, zero for the others -> keep[s*32+j] in {0, 1}), the same for AS and BS, written to
+//   columns 0..63 of T, AT, BT, and R (n x 32 contiguous) = mask .* (A X' - B X' diag(lam)).
+void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const double* BS, const double* C,
+                     const double* keep, const double* lam, const double* mask, double* T, double* AT, double* BT,
+                     double* R);
+bool lobpcg_update32_available();
 void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m);
 // Y = a * d .* X + b * Y  (row scaling by d[i])
 void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,

@@ -2229,6 +2229,106 @@ void block_mul(const Chunks& c, const double* S, int lds_, int p, const double* 
                      q, Y, ldy, accumulate ? 1 : 0);
 }
 
+// ------------------------------------------------------------------------------- fused LOBPCG update (m = 32)
+// One launch for the whole Rayleigh-Ritz update of an iteration:  [X' P'] = S C for S, A S and B S, and the residual
+// block of the next iteration R = mask .* (A X' - B X' diag(lam)).  It uses the structure of C (core.cpp, rr_one):
+//     X' = X Cxx + [P W] Cw ,   P' = keep .* ([P W] Cw)        (Cw = C[32:96, 0:32]; keep_j = 0 for locked pairs)
+// so the [P W] Cw product is computed ONCE per operand (24 MFMAs per 16 x 16 tile pair instead of 48), and A X', B X'
+// never travel back through HBM for the residual kernel (3 block passes).  Wave w of the workgroup owns row tile w >> 1
+// and column tile w & 1 of every 32-row slab; the three operands' slabs go HBM -> registers -> LDS one after the other
+// (next slab's loads in flight during the MFMA phase); the C fragments (24 doubles per lane) stay in registers.
+// Lane maps as k_blockmul_mfma.  Bytes: reads 3 x 96 n, writes 3 x 64 n + 32 n doubles = 4.0 KB per row (separate
+// kernels: 3 x (96 + 64) + (64 + 32) = 4.6 KB); flops 2 n (64 x 32 + 32 x 32) x 3.
+__global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                        const int* __restrict__ csub, const double* __restrict__ S,
+                                                        const double* __restrict__ AS, const double* __restrict__ BS,
+                                                        const double* __restrict__ C, const double* __restrict__ keep,
+                                                        const double* __restrict__ lam, const double* __restrict__ mask,
+                                                        double* __restrict__ T, double* __restrict__ AT,
+                                                        double* __restrict__ BT, double* __restrict__ R) {
+  constexpr int m = 32, p = 96, q = 64, ldS = p + 1, SR = 32;
+  __shared__ double sS[SR * ldS];
+  const int c = blockIdx.x;
+  const int row0 = cstart[c], nrows = clen[c], sd = csub[c];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int rt = w >> 1, ct = w & 1;
+  const double* Cs = C + (int64_t)sd * p * q;
+  const int col = 16 * ct + (l & 15);              // this lane's output column inside X' (and inside P')
+  double bx[8], bw[16];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) bx[kk] = Cs[(int64_t)(4 * kk + (l >> 4)) * q + col];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) bw[kk] = Cs[(int64_t)(m + 4 * kk + (l >> 4)) * q + col];
+  const double kp = keep[sd * m + col], lm = lam[sd * m + col], mk = mask ? mask[sd * m + col] : 1.0;
+  const double* src[3] = {S, AS, BS};
+  double* dst[3] = {T, AT, BT};
+  double rg[SR / 4][2];
+  auto load_slab = [&](int t) {        // t = 3 * slab + operand
+    const double* base = src[t % 3];
+    const int r = (t / 3) * SR;
+#pragma unroll
+    for (int u = 0; u < SR / 4; ++u) {
+      const int rr = r + (SR / 4) * w + u;
+      const bool ok = rr < nrows;
+      const double* srow = base + (int64_t)(row0 + (ok ? rr : 0)) * p;
+      rg[u][0] = ok ? srow[l] : 0.0;
+      rg[u][1] = (ok && l < 32) ? srow[64 + l] : 0.0;
+    }
+  };
+  const int nt = 3 * ((nrows + SR - 1) / SR);
+  load_slab(0);
+  d4 ax = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < nt; ++t) {
+    const int op = t % 3, r = (t / 3) * SR;
+    const int nr = (nrows - r < SR) ? nrows - r : SR;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SR / 4; ++u) {
+      sS[((SR / 4) * w + u) * ldS + l] = rg[u][0];
+      if (l < 32) sS[((SR / 4) * w + u) * ldS + 64 + l] = rg[u][1];
+    }
+    __syncthreads();
+    if (t + 1 < nt) load_slab(t + 1);
+    if (16 * rt < nr) {
+      const double* arow = sS + (16 * rt + (l & 15)) * ldS + (l >> 4);
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[m + 4 * kk], bw[kk], acc, 0, 0, 0);
+      double* out = dst[op];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int rr = 16 * rt + (l >> 4) + 4 * v;
+        if (rr < nr) out[(int64_t)(row0 + r + rr) * p + m + col] = kp * acc[v];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * kk], bx[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int rr = 16 * rt + (l >> 4) + 4 * v;
+        if (rr < nr) out[(int64_t)(row0 + r + rr) * p + col] = acc[v];
+      }
+      if (op == 1) ax = acc;
+      if (op == 2) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int rr = 16 * rt + (l >> 4) + 4 * v;
+          if (rr < nr) R[(int64_t)(row0 + r + rr) * m + col] = mk * (ax[v] - lm * acc[v]);
+        }
+      }
+    }
+  }
+}
+void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const double* BS, const double* C,
+                     const double* keep, const double* lam, const double* mask, double* T, double* AT, double* BT,
+                     double* R) {
+  if (c.nchunk == 0) return;
+  // counted with the block updates it replaces (three of them): same class, bytes and flops of the fused form
+  ProfScope prof(PROF_BLOCKMUL, true, 8.0 * (double)c.n * (3 * 96 + 3 * 64 + 32), 2.0 * (double)c.n * (64 * 32 + 32 * 32) * 3);
+  hipLaunchKernelGGL(k_lobpcg_update32, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, AS, BS, C, keep,
+                     lam, mask, T, AT, BT, R);
+}
+bool lobpcg_update32_available() { return !g_no_mfma; }
+
 // per-chunk column sums -> per-subdomain column sums (fixed order)
 // per-chunk column sums -> per-subdomain column sums: K thread sets per column (chunks c = first + k, + K, ... in
 // order), combined in fixed order -- K independent load streams instead of one dependent chain per column

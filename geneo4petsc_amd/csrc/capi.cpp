@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -626,6 +627,34 @@ long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, i
     g_global_err = e.what();
     return -2;
   }
+}
+
+// test hook of the fused LOBPCG update (m = 32): host arrays in, host arrays out
+PetscErrorCode GeneoTestLobpcgUpdate(int nsub, const int* suboff, const double* S, const double* AS, const double* BS,
+                                     const double* C, const double* keep, const double* lam, const double* mask,
+                                     double* T, double* AT, double* BT, double* R) {
+  GUARD_BEGIN
+  if (!bk::lobpcg_update32_available()) throw std::runtime_error("fused LOBPCG update unavailable (MFMA off)");
+  const int n = suboff[nsub];
+  bk::Chunks c = bk::chunks_upload(nsub, suboff);
+  auto up = [](const double* h, size_t k) {
+    double* d = (double*)bk::alloc(sizeof(double) * std::max<size_t>(1, k));
+    if (h) bk::h2d(d, h, sizeof(double) * k);
+    return d;
+  };
+  const size_t nb = (size_t)n * 96;
+  double *dS = up(S, nb), *dAS = up(AS, nb), *dBS = up(BS, nb), *dC = up(C, (size_t)nsub * 96 * 64);
+  double *dk = up(keep, (size_t)nsub * 32), *dl = up(lam, (size_t)nsub * 32), *dm = up(mask, (size_t)nsub * 32);
+  double *dT = up(nullptr, nb), *dAT = up(nullptr, nb), *dBT = up(nullptr, nb), *dR = up(nullptr, (size_t)n * 32);
+  bk::lobpcg_update32(c, dS, dAS, dBS, dC, dk, dl, dm, dT, dAT, dBT, dR);
+  bk::d2h(T, dT, sizeof(double) * nb);
+  bk::d2h(AT, dAT, sizeof(double) * nb);
+  bk::d2h(BT, dBT, sizeof(double) * nb);
+  bk::d2h(R, dR, sizeof(double) * (size_t)n * 32);
+  for (double* d : {dS, dAS, dBS, dC, dk, dl, dm, dT, dAT, dBT, dR}) bk::dfree(d);
+  bk::chunks_free(c);
+  GUARD_END((PC) nullptr)
+  return 0;
 }
 
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* TC, int q,

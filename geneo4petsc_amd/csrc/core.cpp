@@ -1163,6 +1163,10 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
   std::vector<double> hGAn((size_t)ns * p3 * p3), hGBn((size_t)ns * p3 * p3), hGw((size_t)ns * m * p3);
   bool have_prop = false;
+  bool fused_update = false;  // set below, once the convergence test is known (m = 32, shift-invert test, MFMA on)
+  bool have_R = false;        // the residual block of the current X is already in `cr` (written by the fused update)
+  std::vector<double> keep((size_t)ns * m, 1.0);
+  double* dkeep = nullptr;    // allocated below with the other per-pair device arrays
   static const bool full_gram = getenv("GENEO_LOBPCG_FULL_GRAM") != nullptr;   // experiment: explicit 96 x 96 Grams always
   std::vector<double> nr((size_t)ns * m), na((size_t)ns * m), nb((size_t)ns * m);
   std::vector<std::vector<double>> res(ns, std::vector<double>(m, 1.0));
@@ -1177,6 +1181,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   double* dmask = dv((size_t)ns * m);
   owned_bufs.push_back(dmask);
   bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());   // all ones: the device phase always takes the mask
+  dkeep = dv((size_t)ns * m);
+  owned_bufs.push_back(dkeep);
   void* it_graph[2] = {nullptr, nullptr};                       // HIP graphs of the device phase, one per buffer parity
   bool it_graph_failed = false;
   static const bool no_graph = getenv("GENEO_LOBPCG_NO_GRAPH") != nullptr;
@@ -1280,9 +1286,19 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     t_rr_host += secs(tg1, clk::now());
     bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
-    bk::block_mul(ch, S, p3, p, dC, qout, T, p3, false);
-    bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
-    bk::block_mul(ch, BS, p3, p, dC, qout, BT, p3, false);
+    have_R = false;
+    if (fused_update && p == p3 && with_p) {
+      // one launch: [X' P'] for S, A S, B S (the [P W] product once per operand) and the next residual block
+      for (size_t e = 0; e < keep.size(); ++e) keep[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+      bk::h2d(dkeep, keep.data(), sizeof(double) * keep.size());
+      bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
+      bk::lobpcg_update32(ch, S, AS, BS, dC, dkeep, dlam, dmask, T, AT, BT, cr);
+      have_R = true;
+    } else {
+      bk::block_mul(ch, S, p3, p, dC, qout, T, p3, false);
+      bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
+      bk::block_mul(ch, BS, p3, p, dC, qout, BT, p3, false);
+    }
     std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT);
     return 0;
   };
@@ -1305,6 +1321,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   //   "residual": || r ||_2 <= tol (||A x||_2 + |lambda| ||B x||_2) (round 1; kept for the Chebyshev preconditioner,
   //   which is no approximation of A^-1 on the smooth components, and for checks of B with A = identity).
   const bool conv_sinvert = P.amg && opt.eps_conv != "residual";
+  fused_update = conv_sinvert && m == 32 && bk::lobpcg_update32_available() && !getenv("GENEO_LOBPCG_NO_FUSED_UPDATE");
   int it = 0;
   bool all_done = false;
   std::vector<int> nev_s(ns);
@@ -1384,7 +1401,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     // iterations so that rounding drift (eps * ||A|| ||x|| per update, large for high-contrast
     // operators) cannot accumulate into the residual
     static const int refresh = getenv("GENEO_LOBPCG_REFRESH") ? atoi(getenv("GENEO_LOBPCG_REFRESH")) : 8;
-    if (it > 0 && refresh > 0 && it % refresh == 0) {
+    const bool refreshed = (it > 0 && refresh > 0 && it % refresh == 0);
+    if (refreshed) {
       applyA(S, AS);
       applyB(S, BS);
     }
@@ -1417,8 +1435,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     };
     const bool reduced = have_prop && !full_gram && !(refresh > 0 && it % refresh == 0);
     auto device_phase = [&]() {
-      // one pass: residual block (columns locked in EARLIER iterations come out zero) + the three norms
-      bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);   // norms unused by this test
+      // residual block (columns locked in EARLIER iterations come out zero): already written by the fused update,
+      // unless A X / B X have just been refreshed
+      if (!have_R || refreshed) bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);
       precondition();
       applyA(W, AS + 2 * m);
       applyB(W, BS + 2 * m);
@@ -1451,7 +1470,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       // it 0 runs direct (first calls size scratch buffers); while bench.py's in-situ kernel timer is on every 8th
       // iteration runs direct so that its launches can be bracketed by events (graph nodes cannot)
       const int par = it & 1;
-      const bool direct = no_graph || !reduced || (bk::spmv_profiling() && it % 8 == 1);
+      const bool direct = no_graph || !reduced || (fused_update && !have_R) || (bk::spmv_profiling() && it % 8 == 1);
       if (!direct && !it_graph[par] && !it_graph_failed) {
         const int spmm_before = info.eig_spmm;
         if (bk::graph_capture_begin()) {

@@ -268,6 +268,13 @@ long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, i
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* T_or_C,
                                 int q, double* out, int reps, double* ms_avg);
 
+/* fused Rayleigh-Ritz update of one LOBPCG iteration, m = 32 (test hook; host arrays): S, AS, BS n x 96 row-major
+ * [X | P | W]; C nsub x 96 x 64; keep / lam / mask nsub x 32.  Out: columns 0..63 of T, AT, BT (n x 96) = [X' P'] of each
+ * operand, R (n x 32) = mask .* (A X' - B X' diag(lam)). */
+PetscErrorCode GeneoTestLobpcgUpdate(int nsub, const int* suboff, const double* S, const double* AS, const double* BS,
+                                     const double* C, const double* keep, const double* lam, const double* mask,
+                                     double* T, double* AT, double* BT, double* R);
+
 #ifdef __cplusplus
 }
 #endif

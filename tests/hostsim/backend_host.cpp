@@ -506,5 +506,31 @@ void* event_create() { return nullptr; }
 void event_record(void*) {}
 float event_elapsed_ms(void*, void*) { return 0.f; }
 void event_destroy(void*) {}
+bool lobpcg_update32_available() { return true; }
+void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const double* BS, const double* C,
+                     const double* keep, const double* lam, const double* mask, double* T, double* AT, double* BT,
+                     double* R) {
+  const double* src[3] = {S, AS, BS};
+  double* dst[3] = {T, AT, BT};
+  std::vector<double> ax(32), pw(32);
+  for (int s = 0; s < c.nsub; ++s)
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+      for (int op = 0; op < 3; ++op) {
+        const double* row = src[op] + (int64_t)i * 96;
+        const double* Cs = C + (int64_t)s * 96 * 64;
+        double* out = dst[op] + (int64_t)i * 96;
+        for (int j = 0; j < 32; ++j) {
+          double w = 0.0;
+          for (int k = 32; k < 96; ++k) w += row[k] * Cs[(int64_t)k * 64 + j];
+          double x = w;
+          for (int k = 0; k < 32; ++k) x += row[k] * Cs[(int64_t)k * 64 + j];
+          pw[j] = keep[s * 32 + j] * w;
+          out[j] = x;
+          if (op == 1) ax[j] = x;
+          if (op == 2) R[(int64_t)i * 32 + j] = (mask ? mask[s * 32 + j] : 1.0) * (ax[j] - lam[s * 32 + j] * x);
+        }
+        for (int j = 0; j < 32; ++j) out[32 + j] = pw[j];
+      }
+}
 
 }  // namespace bk

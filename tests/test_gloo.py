@@ -44,4 +44,5 @@ def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     assert meta["its"] == res.its, (meta["its"], res.its)      # identical, CG included (no tolerance on the count)
     np.testing.assert_allclose(got["m"], orc.matmult(b), rtol=1e-12, atol=1e-9)
     assert np.linalg.norm(got["y"] - orc.apply(b)) <= 1e-9 * np.linalg.norm(orc.apply(b))
-    assert np.linalg.norm(got["x"] - res.x) <= 1e-7 * np.linalg.norm(res.x)
+    # two iterates of the same count: to the Krylov tolerance for CG (cases.Tight: amplified rounding), 1e-7 for GMRES
+    assert np.linalg.norm(got["x"] - res.x) <= (1e-6 if ksp == "cg" else 1e-7) * np.linalg.norm(res.x)

@@ -187,3 +187,34 @@ def test_device_sparse_product_reports_overflow(lib):
     a2 = sp.csr_matrix(np.ones((2, 200)))
     c = sparse_product(a2, sp.eye(200, format="csr"), lib)
     assert c is not None and abs(c - a2).max() == 0.0
+
+
+def test_fused_lobpcg_update(lib):
+    """k_lobpcg_update32: [X' P'] = S C for S, AS, BS with the [P W] product shared between X' and P', and the next
+    residual block, against numpy.  C has the structure core.cpp gives it (P columns = X columns on the P / W rows for
+    kept pairs, zero otherwise); two subdomains with ragged sizes (chunk tails, a partial 32-row slab)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    suboff = np.array([0, 1500, 1500 + 1061], dtype=np.int32)
+    n, ns = int(suboff[-1]), 2
+    S, AS, BS = (rng.random((n, 96)) - 0.5 for _ in range(3))
+    Cm = np.zeros((ns, 96, 64))
+    keep = (rng.random((ns, 32)) > 0.3).astype(np.float64)
+    Cm[:, :, :32] = rng.random((ns, 96, 32)) - 0.5
+    Cm[:, 32:, 32:] = Cm[:, 32:, :32] * keep[:, None, :]
+    lam = rng.random((ns, 32)) + 0.1
+    mask = (rng.random((ns, 32)) > 0.2).astype(np.float64)
+    T, AT, BT = (np.zeros((n, 96)) for _ in range(3))
+    R = np.zeros((n, 32))
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(C.c_double))
+    args = [S, AS, BS, Cm, keep, lam, mask]
+    keepalive = [np.ascontiguousarray(a) for a in args]
+    rc = lib.GeneoTestLobpcgUpdate(ns, suboff.ctypes.data_as(C.POINTER(C.c_int)), *[p(a) for a in keepalive],
+                                   p(T), p(AT), p(BT), p(R))
+    assert rc == 0, lib.PCGenEOGetError(None).decode()
+    for s in range(ns):
+        rows = slice(suboff[s], suboff[s + 1])
+        for src, out in ((S, T), (AS, AT), (BS, BT)):
+            np.testing.assert_allclose(out[rows, :64], src[rows] @ Cm[s], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(R[rows], mask[s] * ((AS[rows] @ Cm[s])[:, :32] - lam[s] * (BS[rows] @ Cm[s])[:, :32]),
+                                   rtol=1e-12, atol=1e-12)
