@@ -341,6 +341,283 @@ def _refine_bisection(g: sp.csr_matrix, nodes: np.ndarray, side: np.ndarray, pas
     return side
 
 
+# ---- multilevel bisection (the scheme Metis itself uses: Karypis & Kumar, SIAM J. Sci. Comput. 20, 1998) ----------
+def _hem_coarsen(g: sp.csr_matrix, w: np.ndarray):
+    """One level of heavy-edge matching, vectorised as a handshake: every free vertex proposes to its heaviest free
+    neighbour (ties broken by a symmetric hash of the edge), mutual proposals are matched, a few rounds.
+    Returns (coarse graph, coarse vertex weights, fine -> coarse map)."""
+    n = g.shape[0]
+    indptr, indices = g.indptr, g.indices
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+    lo, hi = np.minimum(rows, indices), np.maximum(rows, indices)
+    noise = ((lo * 2654435761 + hi * 40503) % 1000003) / 1000003.0
+    # heavy edges between LIGHT vertices first, and no pair heavier than 3x the average: plain heavy-edge matching lets a
+    # few clusters swallow their neighbourhood (one coarse vertex of 5 % of a 30^3 grid), which ruins the coarse cuts
+    wgt = g.data.astype(np.float64) / (w[rows] * w[indices]) * (1.0 + 1e-3 * noise)
+    wgt[w[rows] + w[indices] > 3.0 * float(w.sum()) / n] = -1.0
+    starts = indptr[:-1]
+    nonempty = np.diff(indptr) > 0
+    match = np.full(n, -1, dtype=np.int64)
+    big = len(wgt)
+    for _ in range(8):
+        free = match < 0
+        valid = free[rows] & free[indices] & (wgt > 0.0)
+        if not valid.any():
+            break
+        wv = np.where(valid, wgt, -1.0)
+        rmax = np.full(n, -1.0)
+        rmax[nonempty] = np.maximum.reduceat(wv, starts[nonempty])
+        pos = np.where(valid & (wv == rmax[rows]), np.arange(big), big)
+        first = np.full(n, big, dtype=np.int64)
+        first[nonempty] = np.minimum.reduceat(pos, starts[nonempty])
+        v = np.flatnonzero(first < big)
+        if len(v) == 0:
+            break
+        pick = np.full(n, -1, dtype=np.int64)
+        pick[v] = indices[first[v]]
+        u = pick[v]
+        mutual = v[(pick[u] == v) & (v < u)]
+        if len(mutual) == 0:
+            break
+        match[mutual] = pick[mutual]
+        match[pick[mutual]] = mutual
+    rep = np.where(match < 0, np.arange(n), np.minimum(np.arange(n), match))
+    _, cmap = np.unique(rep, return_inverse=True)
+    nc = int(cmap.max()) + 1
+    pm = sp.csr_matrix((np.ones(n), (np.arange(n), cmap)), shape=(n, nc))
+    gc = (pm.T @ g @ pm).tocsr()
+    gc.setdiag(0)
+    gc.eliminate_zeros()
+    return gc, np.bincount(cmap, weights=w, minlength=nc), cmap
+
+
+def _cut_weight(g: sp.csr_matrix, side: np.ndarray) -> float:
+    s = side.astype(np.float64)
+    return float(s @ (g @ (1.0 - s)))
+
+
+def _grow_bisection(g: sp.csr_matrix, w: np.ndarray, target_a: float) -> np.ndarray:
+    """Initial bisection of the coarsest graph: greedy graph growing from several seeds (the region takes the frontier
+    vertex that adds the least cut until it holds target_a of the weight), the smallest cut wins."""
+    from scipy.sparse.csgraph import breadth_first_order
+    n = g.shape[0]
+    dense = g.toarray() if n <= 400 else None
+    order0 = breadth_first_order(g, 0, directed=False, return_predecessors=False)
+    seeds = list(dict.fromkeys([int(order0[-1]), 0, int(order0[len(order0) // 2])] + list(range(0, n, max(1, n // 5)))))
+    best, best_cut = None, None
+    for seed in seeds[:8]:
+        in_a = np.zeros(n, dtype=bool)
+        in_a[seed] = True
+        wa = w[seed]
+        conn = (dense[seed].copy() if dense is not None else np.asarray(g[seed].todense()).ravel())    # weight to A
+        deg = np.asarray(g.sum(axis=1)).ravel()
+        while wa < target_a:
+            gain = 2.0 * conn - deg                      # cut change if v joins A, negated
+            gain[in_a] = -np.inf
+            front = conn > 0
+            front[in_a] = False
+            cand = np.flatnonzero(front) if front.any() else np.flatnonzero(~in_a)
+            if len(cand) == 0:
+                break
+            v = int(cand[np.argmax(gain[cand])])
+            in_a[v] = True
+            wa += w[v]
+            conn += dense[v] if dense is not None else np.asarray(g[v].todense()).ravel()
+        side = ~in_a
+        cut = _cut_weight(g, side)
+        if best_cut is None or cut < best_cut:
+            best, best_cut = side, cut
+    # spectral candidates: the lowest non-trivial eigenvectors of the weighted Laplacian (dense: the graph is tiny) and
+    # their pairwise sums / differences (a cube's Fiedler value is threefold: the axis-aligned cut is a combination),
+    # each split at the weighted median and polished by the boundary refinement
+    if 8 <= n <= 600:
+        lap = -(dense if dense is not None else g.toarray()).astype(np.float64)
+        lap[np.arange(n), np.arange(n)] = -lap.sum(axis=1)
+        sw = 1.0 / np.sqrt(w)
+        _, vec = np.linalg.eigh(lap * sw[:, None] * sw[None, :])
+        vs = [vec[:, k] * sw for k in range(1, min(4, n))]
+        cands = list(vs) + [a + sgn * b for i, a in enumerate(vs) for b in vs[i + 1:] for sgn in (1.0, -1.0)]
+        for f in cands:
+            order = np.argsort(f, kind="stable")
+            cum = np.cumsum(w[order])
+            side = np.ones(n, dtype=bool)
+            side[order[:max(1, int(np.searchsorted(cum, target_a)) + 1)]] = False
+            side = _fm_refine(g, w, side, target_a, 0.03)
+            cut = _cut_weight(g, side)
+            if cut < best_cut:
+                best, best_cut = side, cut
+    return best
+
+
+def _fm_refine(g: sp.csr_matrix, w: np.ndarray, side: np.ndarray, target_a: float, tol: float, passes: int = 6) -> np.ndarray:
+    """Boundary refinement of a weighted bisection (side False = A), vectorised Fiduccia-Mattheyses flavour: per pass
+    the positive-gain boundary vertices are visited best first, a vertex moves when the weight of A stays within tol of
+    its target (or gets closer to it) and no neighbour moved in this pass (so the gains used are still exact)."""
+    side = side.copy()
+    deg = np.asarray(g.sum(axis=1)).ravel()
+    total = float(w.sum())
+    for _ in range(passes):
+        to_b = g @ side.astype(np.float64)
+        ext = np.where(side, deg - to_b, to_b)
+        gain = 2.0 * ext - deg
+        wa = float(w[~side].sum())
+        cand = np.flatnonzero((ext > 0) & (gain >= 0))
+        if len(cand) == 0:
+            break
+        cand = cand[np.argsort(-gain[cand], kind="stable")]
+        blocked = np.zeros(len(side), dtype=bool)
+        moved = 0
+        for v in cand[:max(64, 4 * int(np.sqrt(len(side))) + len(cand) // 4)]:
+            if blocked[v]:
+                continue
+            dwa = w[v] if side[v] else -w[v]            # joining A adds its weight to A
+            new_dev, old_dev = abs(wa + dwa - target_a), abs(wa - target_a)
+            if new_dev > tol * total and new_dev >= old_dev:
+                continue
+            if gain[v] == 0 and new_dev >= old_dev:
+                continue
+            side[v] = not side[v]
+            wa += dwa
+            blocked[v] = True
+            blocked[g.indices[g.indptr[v]:g.indptr[v + 1]]] = True
+            moved += 1
+        if moved == 0:
+            break
+    return side
+
+
+def _balance_exact(g: sp.csr_matrix, side: np.ndarray, n_a: int) -> np.ndarray:
+    """Unit weights: move the cheapest boundary vertices until side A holds exactly n_a vertices."""
+    side = side.copy()
+    deg = np.asarray(g.sum(axis=1)).ravel()
+    for _ in range(len(side)):
+        na = int((~side).sum())
+        if na == n_a:
+            break
+        from_b = na < n_a                                # A too small: take vertices from B
+        to_b = g @ side.astype(np.float64)
+        ext = np.where(side, deg - to_b, to_b)
+        gain = 2.0 * ext - deg
+        pool = np.flatnonzero((side == from_b) & (ext > 0))
+        if len(pool) == 0:
+            pool = np.flatnonzero(side == from_b)
+        k = min(abs(n_a - na), max(1, len(pool) // 8))
+        pick = pool[np.argsort(-gain[pool], kind="stable")][:k]
+        # an independent set, so that the gains stay exact
+        take, blocked = [], np.zeros(len(side), dtype=bool)
+        for v in pick:
+            if not blocked[v]:
+                take.append(v)
+                blocked[v] = True
+                blocked[g.indices[g.indptr[v]:g.indptr[v + 1]]] = True
+        side[take] = not from_b
+    return side
+
+
+def _spectral_bisect(g: sp.csr_matrix, n_a: int):
+    """Multilevel SPECTRAL bisection (Barnard & Simon): the lowest non-trivial eigenvectors of the graph Laplacian are
+    computed on the coarsest graph of the matching hierarchy (dense), prolonged level by level and smoothed with a few
+    damped-Jacobi sweeps of the Laplacian.  A smooth function cut at a quantile gives a smooth interface -- what the
+    matching-based cut lacks (its coarse vertices are ragged blobs: 2.3x the planar cut on a 30^3 grid at the coarsest
+    level, still 1.4x after refinement).  Three vectors are kept because symmetric domains have a multiple Fiedler
+    value (a cube: threefold) and the good cut is a COMBINATION of them: the direction in their span is searched for
+    the smallest cut.  Returns the side array (False = the n_a vertices with the lowest values) or None."""
+    n = g.shape[0]
+    levels, gl, wl = [], g.astype(np.float64), np.ones(n)
+    while gl.shape[0] > 150:
+        gc, wc, cmap = _hem_coarsen(gl, wl)
+        if gc.shape[0] > 0.9 * gl.shape[0]:
+            break
+        levels.append((gl, wl, cmap))
+        gl, wl = gc, wc
+    nc = gl.shape[0]
+    if nc > 2500 or nc < 8:
+        return None
+    lap = -gl.toarray()
+    lap[np.arange(nc), np.arange(nc)] = -lap.sum(axis=1)
+    sw = 1.0 / np.sqrt(wl)
+    _, vec = np.linalg.eigh(lap * sw[:, None] * sw[None, :])
+    x = vec[:, 1:4] * sw[:, None]
+    for gf, wf, cmap in reversed(levels):
+        x = x[cmap]
+        deg = np.asarray(gf.sum(axis=1)).ravel()
+        dinv = 1.0 / np.maximum(deg, 1e-300)
+        for _ in range(10):
+            x = x - 0.7 * (dinv[:, None] * (deg[:, None] * x - gf @ x))
+            x = x - (wf @ x) / wf.sum()
+    # orthonormalise the smoothed vectors, then search the direction
+    q, _ = np.linalg.qr(x)
+    rows = np.repeat(np.arange(n), np.diff(g.indptr))
+    cols = g.indices
+    upper = rows < cols
+    ru, cu = rows[upper], cols[upper]
+
+    def cut_of(d):
+        f = q @ d
+        thr = np.partition(f, n_a - 1)[n_a - 1]
+        sd = f > thr
+        return int(np.count_nonzero(sd[ru] != sd[cu])), f
+
+    k = q.shape[1]
+    dirs = []
+    if k == 1:
+        dirs = [np.array([1.0])]
+    else:
+        m = 64                                            # Fibonacci half-sphere (k = 3) / half-circle (k = 2)
+        for i in range(m):
+            if k == 2:
+                t = np.pi * i / m
+                dirs.append(np.array([np.cos(t), np.sin(t)]))
+            else:
+                z = (i + 0.5) / m
+                r = np.sqrt(max(0.0, 1.0 - z * z))
+                phi = i * np.pi * (3.0 - np.sqrt(5.0))
+                dirs.append(np.array([r * np.cos(phi), r * np.sin(phi), z]))
+    best_d, best_c = None, None
+    for d in dirs:
+        c, _ = cut_of(d)
+        if best_c is None or c < best_c:
+            best_d, best_c = d, c
+    step = 0.2
+    for _ in range(5):                                    # local search around the best direction
+        improved = False
+        for axis in range(k):
+            for sgn in (1.0, -1.0):
+                d = best_d.copy()
+                d[axis] += sgn * step
+                d /= np.linalg.norm(d)
+                c, _ = cut_of(d)
+                if c < best_c:
+                    best_d, best_c, improved = d, c, True
+        if not improved:
+            step *= 0.5
+    _, f = cut_of(best_d)
+    order = np.argsort(f, kind="stable")
+    side = np.ones(n, dtype=bool)
+    side[order[:n_a]] = False
+    return side
+
+
+def _multilevel_bisect(g: sp.csr_matrix, n_a: int) -> np.ndarray:
+    """Bisection of g (unit vertex weights) with exactly n_a vertices on side False: coarsen by heavy-edge matching to
+    ~100 vertices, grow the initial cut there, project back level by level with boundary refinement."""
+    n = g.shape[0]
+    levels, gl, wl = [], g.astype(np.float64), np.ones(n)
+    while gl.shape[0] > 120:
+        gc, wc, cmap = _hem_coarsen(gl, wl)
+        if gc.shape[0] > 0.9 * gl.shape[0]:
+            break                                        # matching stalled (stars, cliques)
+        levels.append((gl, wl, cmap))
+        gl, wl = gc, wc
+    frac = n_a / float(n)
+    side = _grow_bisection(gl, wl, frac * wl.sum())
+    side = _fm_refine(gl, wl, side, frac * wl.sum(), 0.03)
+    for gf, wf, cmap in reversed(levels):
+        side = side[cmap]
+        side = _fm_refine(gf, wf, side, frac * wf.sum(), 0.02)
+    return _balance_exact(g, side, n_a)
+
+
 def partition_graph(g: sp.csr_matrix, nb_part: int, refine: bool = True) -> np.ndarray:
     """Deterministic k-way partition by recursive level-structure bisection + boundary smoothing: the bisections
     are balanced to one vertex; absorbing stray fragments afterwards may shift a few vertices (a few % at most,
@@ -372,10 +649,20 @@ def partition_graph(g: sp.csr_matrix, nb_part: int, refine: bool = True) -> np.n
         side[pos[n1:]] = True
         if refine and len(nodes) > 8:
             from scipy.sparse.csgraph import connected_components
-            ncomp = lambda sd: sum(connected_components(g[nodes[m]][:, nodes[m]])[0] for m in (sd, ~sd))
+            sub = g[nodes][:, nodes].tocsr()
+            ncomp = lambda sd: sum(connected_components(sub[m][:, m])[0] for m in (sd, ~sd))
             better = _refine_bisection(g, nodes, side)
             if ncomp(better) <= ncomp(side):             # smoothing must not tear a part into pieces
                 side = better
+            if len(nodes) >= 64 and connected_components(sub)[0] == 1:
+                # multilevel bisections -- matching + graph growing + boundary refinement, and multilevel spectral --:
+                # the smallest cut wins, provided it does not tear a part into more pieces
+                for cand in (_multilevel_bisect(sub, n1), _spectral_bisect(sub, n1)):
+                    if cand is None:
+                        continue
+                    cand = _balance_exact(sub, _fm_refine(sub.astype(np.float64), np.ones(len(nodes)), cand, float(n1), 0.002), n1)
+                    if _cut_weight(sub, cand) < _cut_weight(sub, side) and ncomp(cand) <= max(2, ncomp(side)):
+                        side = cand
         stack.append((nodes[~side], first, k1))
         stack.append((nodes[side], first + k1, k - k1))
     return _absorb_fragments(g, part, nb_part) if refine else part

@@ -107,7 +107,8 @@ def test_rank_plans_cover_every_halo():
 @pytest.mark.parametrize("n,k", [(10, 8), (9, 5)])
 def test_kway_partitioner(n, k, dual):
     """Stand-in for METIS_PartMeshDual / Nodal (driver:381-445): balanced within 5 %, connected parts,
-    deterministic, cut within 2.5x of the structured blocks on a cube."""
+    deterministic, and -- with the multilevel spectral bisection of round 2 -- the cut of the structured 2x2x2 blocks
+    on a cube, i.e. the optimum (round 1: within 2.5x)."""
     from scipy.sparse.csgraph import connected_components
     mesh = decomp.grid_mesh(size=n, dim=3)
     g = decomp.mesh_graph(mesh, dual)
@@ -120,7 +121,7 @@ def test_kway_partitioner(n, k, dual):
     assert np.array_equal(p, decomp.partition_graph(g, k))
     if not dual and k == 8:
         blocks = decomp.structured_node_partition(n, 3, (2, 2, 2))
-        assert decomp.edge_cut(g, p) <= 2.5 * decomp.edge_cut(g, blocks)
+        assert decomp.edge_cut(g, p) <= 1.05 * decomp.edge_cut(g, blocks)
     ep, npart = decomp.partition_mesh(mesh, k, dual)
     dec = decomp.decompose(mesh, k, ep, npart, dual, 1)
     assert len(dec.domains) == k and all(len(d.l2g) > 0 for d in dec.domains)
