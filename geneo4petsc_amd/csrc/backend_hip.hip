@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
 }
 
 int spmv_kind();
+static bool g_force_slices = false;   // tests: no lanes-per-row kernel for small ragged matrices (they exercise the wide-slice kernels)
 static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col = nullptr);
 
 Csr csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
@@ -426,7 +427,8 @@ static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
     // Long or ragged rows (restriction operators, coarse Galerkin matrices): one lane group per row reads the
     // row coalesced and reduces with shuffles; the slices would pad every 64-row slice to its longest row.
     const double avg = n > 0 ? (double)a.nnz / n : 0.0;
-    if (n < SELL_VEC_MAX_ROWS && (a.nlong > 0 || avg >= 20.0)) a.vec_lpr = avg <= 24.0 ? 16 : (avg <= 48.0 ? 32 : 64);
+    static const int vec_max_rows = getenv("GENEO_SELL_VEC_MAX_ROWS") ? atoi(getenv("GENEO_SELL_VEC_MAX_ROWS")) : SELL_VEC_MAX_ROWS;
+    if (!g_force_slices && n < vec_max_rows && (a.nlong > 0 || avg >= 20.0)) a.vec_lpr = avg <= 24.0 ? 16 : (avg <= 48.0 ? 32 : 64);
     a.long_rows = (int*)alloc(sizeof(int) * std::max<size_t>(1, longr.size()));
     h2d(a.long_rows, longr.data(), sizeof(int) * longr.size());
   }
@@ -903,6 +905,76 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
     y[r] = bb - w * sum;
   }
 }
+// Wide slices (coarse Galerkin operators, restrictions: 30-60 entries per row on a few thousand slices): with one wave
+// per slice the wave's own chain of dependent (col,val) -> x loads is the whole run time and most of the chip idles.
+// Here ONE WORKGROUP owns a slice: wave w takes the entries k = w, w + 4, ... (4 of them in flight per lane, 16 per row
+// across the workgroup), the four partial sums meet in LDS and wave 0 runs the epilogue.  Summation order is fixed.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_spmv_sell_wide(const int64_t* __restrict__ sl_ptr, int nslice, int n,
+                                                        const int* __restrict__ col, const double* __restrict__ val,
+                                                        const double* __restrict__ x, double* __restrict__ y,
+                                                        const double* __restrict__ b, double* __restrict__ z,
+                                                        const double* __restrict__ dinv, double w,
+                                                        const double* __restrict__ cs) {
+  constexpr int UNR = 4;
+  __shared__ double part[3][64];
+  const int s = xcd_remap(blockIdx.x, nslice);
+  if (s >= nslice) return;
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
+  const double* __restrict__ xin = (EPI == EPI_PRE) ? b : x;
+  double acc[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
+  int64_t e = a + 64 * wv + l;
+  for (; e + 256 * (UNR - 1) < e1; e += 256 * UNR) {
+    int c[UNR];
+    double v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      c[u] = col[e + 256 * u];
+      v[u] = val[e + 256 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc[u] += v[u] * ((EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]]);
+  }
+  for (; e < e1; e += 256) {
+    const int c0 = col[e];
+    acc[0] += val[e] * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
+  }
+  double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (wv > 0) part[wv - 1][l] = sum;
+  __syncthreads();
+  if (wv > 0) return;
+  sum = (sum + part[0][l]) + (part[1][l] + part[2][l]);
+  const int r = 64 * s + l;
+  if (r >= n) return;
+  if (EPI == EPI_NONE) {
+    y[r] = sum;
+  } else if (EPI == EPI_RES) {
+    y[r] = b[r] - sum;
+  } else if (EPI == EPI_ADD) {
+    y[r] = z[r] + sum;
+  } else if (EPI == EPI_JAC) {
+    y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else {  // EPI_PRE
+    const double bb = b[r];
+    z[r] = w * dinv[r] * bb;
+    y[r] = bb - w * sum;
+  }
+}
+static int g_sell_wide = -1;     // average slice width from which a workgroup (not a wave) owns a slice; 0 = never
+static inline bool sell_wide(const Csr& a) {
+  if (g_sell_wide < 0) g_sell_wide = getenv("GENEO_SELL_WIDE") ? atoi(getenv("GENEO_SELL_WIDE")) : 16;
+  return g_sell_wide > 0 && a.nslice > 0 && a.nlong == 0 && a.sl_nnz >= (int64_t)64 * g_sell_wide * a.nslice;
+}
+template <int EPI>
+static void spmv_wide_launch(const Csr& a, const double* x, double* y, const double* b, double* z, const double* dinv,
+                             double w) {
+  const int per = (a.nslice + 7) / 8;
+  hipLaunchKernelGGL((k_spmv_sell_wide<EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, a.sl_col,
+                     a.sl_val, x, y, b, z, dinv, w, a.col_scaled ? (const double*)nullptr : dinv);
+}
 // Lanes-per-row CSR kernel for long / ragged rows, with the same epilogues: LPR lanes stride over one row
 // (coalesced col/val reads), partial sums are combined by a fixed butterfly, lane 0 writes.
 template <int LPR, int EPI>
@@ -975,9 +1047,10 @@ int spmv_kind() {
   return g_spmv_kind;
 }
 const char* spmv_kernel_name() { return spmv_kind() == 0 ? "k_spmv_lds" : "k_spmv_sell"; }
-void set_spmv_kind(int kind) {
+void set_spmv_kind(int kind) {     // kind = layout + 10 * variant + 100 * (1: ragged matrices keep the slices too)
   g_spmv_kind = (kind % 10) ? 1 : 0;
-  g_sell_variant = kind / 10;
+  g_sell_variant = (kind / 10) % 10;
+  g_force_slices = (kind / 100) % 10 == 1;
 }
 
 // In-situ kernel timing (bench.py): while profiling is on, every `every`-th launch of each kernel class is bracketed by
@@ -1096,6 +1169,8 @@ void spmv(const Csr& a, const double* x, double* y) {
                        a.col, a.val, x, y);
   } else if (a.vec_lpr > 0) {
     spmv_vec_launch<EPI_NONE>(a, x, y, nullptr, nullptr, nullptr, 0.0);
+  } else if (sell_wide(a)) {
+    spmv_wide_launch<EPI_NONE>(a, x, y, nullptr, nullptr, nullptr, 0.0);
   } else {
     const int nwb = (a.nslice + 3) / 4;
     const int perw = (nwb + 7) / 8;
@@ -1311,6 +1386,88 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
   }
 }
 
+// Wide slices (see k_spmv_sell_wide): one workgroup per slice.  The four waves stage a chunk of KC entries per row
+// together (each entry of the slice is read ONCE -- the wave-per-slice kernel above re-stages a wide slice for every row
+// group), then wave w accumulates the rows 16 w .. 16 w + 15 of the slice: 64 / LG rows per wave-wide gather, all its
+// row groups and 8 entries in flight at a time.
+template <int LG, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
+                                                        const double* __restrict__ sl_val, int n, int nslice,
+                                                        const double* __restrict__ X, int ldx, double* __restrict__ Y, int ldy,
+                                                        const double* __restrict__ pre, const double* __restrict__ post,
+                                                        const double* __restrict__ B, int ldb, double* __restrict__ Z, int ldz,
+                                                        const double* __restrict__ dinv, double w) {
+  typedef spmm_d2 d2;
+  constexpr int KC = 16;             // entries per row staged per chunk
+  constexpr int RS = 64 / LG;        // rows per wave-wide load
+  constexpr int U = 16 / RS;         // row groups of one wave (its 16 rows)
+  __shared__ int lc[KC * 64];
+  __shared__ double lv[KC * 64];
+  const int s = xcd_remap(blockIdx.x, nslice);
+  if (s >= nslice) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / LG, q = lane % LG;
+  const double* Xq = X + 2 * q;
+  const int64_t base = sl_ptr[s];
+  const int wd = (int)((sl_ptr[s + 1] - base) >> 6);
+  d2 acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc[u] = d2{0.0, 0.0};
+  const int rl0 = 16 * wave + grp;
+  for (int k0 = 0; k0 < wd; k0 += KC) {
+    const int kc = (wd - k0 < KC) ? wd - k0 : KC;
+    if (k0 > 0) __syncthreads();
+    for (int k = wave; k < kc; k += 4) {
+      const int64_t e = base + (int64_t)64 * (k0 + k) + lane;
+      const int c = sl_col[e];
+      double v = sl_val[e];
+      if (pre) v *= pre[c];
+      lc[k * 64 + lane] = c;
+      lv[k * 64 + lane] = v;
+    }
+    __syncthreads();
+    for (int kb = 0; kb < kc; kb += 8) {
+      const int kw = (kc - kb < 8) ? kc - kb : 8;
+      const int* mc = lc + kb * 64;
+      const double* mv = lv + kb * 64;
+      switch (kw) {                         // workgroup-uniform
+        case 8: spmm_sell_accum<LG, U, 8>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 7: spmm_sell_accum<LG, U, 7>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 6: spmm_sell_accum<LG, U, 6>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 5: spmm_sell_accum<LG, U, 5>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 4: spmm_sell_accum<LG, U, 4>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 3: spmm_sell_accum<LG, U, 3>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 2: spmm_sell_accum<LG, U, 2>(mc, mv, rl0, Xq, ldx, acc); break;
+        case 1: spmm_sell_accum<LG, U, 1>(mc, mv, rl0, Xq, ldx, acc); break;
+        default: break;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t r = (int64_t)64 * s + 16 * wave + u * RS + grp;
+    if (r >= n) continue;
+    d2 a2 = acc[u];
+    if (post) a2 *= post[r];
+    d2 out;
+    if (EPI == EPI_NONE) {
+      out = a2;
+    } else if (EPI == EPI_RES) {
+      out = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2;
+    } else if (EPI == EPI_ADD) {
+      out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) + a2;
+    } else if (EPI == EPI_JAC) {
+      out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
+            (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+    } else {  // EPI_PRE: X = B, pre = dinv
+      const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
+      *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
+      out = bb - w * a2;
+    }
+    *reinterpret_cast<d2*>(Y + r * ldy + 2 * q) = out;
+  }
+}
+
 static int g_spmm_wpx = -1;      // workgroups per XCD group of the sliced SpMM (GENEO_SPMM_WPX; 0 = old CSR kernel)
 static int g_spmm_u = 2;         // steps in flight per wave (GENEO_SPMM_U: 1, 2 or 4)
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -1332,6 +1489,15 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
   if (m != 16 && m != 32 && m != 64) return false;
   if ((ldx | ldy | ldb | ldz) & 1) return false;
   if (!aligned16(X) || !aligned16(Y) || !aligned16(B) || !aligned16(Z)) return false;
+  if (sell_wide(a)) {
+    const int per = (a.nslice + 7) / 8;
+#define SELLW(L)                                                                                                           \
+  hipLaunchKernelGGL((k_spmm_sell_wide<L, EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
+                     a.nslice, X, ldx, Y, ldy, pre, post, B, ldb, Z, ldz, dinv, w)
+    if (m == 16) { SELLW(8); return true; }
+    if (m == 32) { SELLW(16); return true; }
+#undef SELLW
+  }
   // small matrices: no more workgroups than there is work for (4 slices per workgroup and pass)
   int wpx = g_spmm_wpx;
   const int need = (a.nslice + 31) / 32;
@@ -1387,6 +1553,10 @@ static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int 
   if (m == 1 && ldx <= 1 && ldy == 1 && ldb <= 1 && ldz <= 1 && csr_fusable(a)) {  // contiguous vectors: SpMV kernels
     if (a.vec_lpr > 0) {
       spmv_vec_launch<EPI>(a, X, Y, B, Z, dinv, w);
+      return;
+    }
+    if (sell_wide(a)) {
+      spmv_wide_launch<EPI>(a, X, Y, B, Z, dinv, w);
       return;
     }
     const int nwb = (a.nslice + 3) / 4;

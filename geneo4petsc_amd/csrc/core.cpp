@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <fstream>
@@ -1161,7 +1162,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(*P.B, X, p3, Y, p3, m, P.Bs, P.Bs); info.eig_spmm++; };
 
   std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
-  std::vector<double> hGAn((size_t)ns * p3 * p3), hGBn((size_t)ns * p3 * p3), hGw((size_t)ns * m * p3);
+  std::vector<double> hGw((size_t)ns * m * p3);
   bool have_prop = false;
   bool fused_update = false;  // set below, once the convergence test is known (m = 32, shift-invert test, MFMA on)
   bool have_R = false;        // the residual block of the current X is already in `cr` (written by the fused update)
@@ -1190,7 +1191,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   double* dn3 = dv((size_t)ns * 3 * m);
   owned_bufs.push_back(dn3);
   std::vector<double> n3((size_t)ns * 3 * m);
-  double t_rr_host = 0.0, t_dev_wait = 0.0;
+  double t_rr_host = 0.0, t_dev_wait = 0.0, t_prop_host = 0.0;
+  bool conv_sinvert_now = false;   // set with conv_sinvert below: the propagated Gram blocks are only used on that path
   auto t_lob0 = clk::now();
   // Gram blocks of the leading p columns, symmetrised on the host
   auto gram_blocks = [&](int p) {
@@ -1201,9 +1203,66 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p * p);
     t_dev_wait += secs(tg0, clk::now());
   };
+  // The Gram blocks of the NEW [X P] follow from the old ones: [X' P'] = S C  =>  [X' P']^T A [X' P'] = C^T G_A C.
+  // Only the W rows of the next Gram matrices then need the GPU (a third of the flops, 5 block passes instead of
+  // 12); the explicit 96 x 96 products come back every `refresh` iterations together with the explicit A X, B X.
+  // The products run on the host AFTER the device part of the next iteration has been launched (run_propagate below):
+  // they are needed only when its Gram rows come back, so they cost no GPU idle time.
+  std::vector<double> hSA((size_t)ns * p3 * p3), hSB((size_t)ns * p3 * p3);   // symmetrised blocks the last RR used
+  bool prop_pending = false;
+  auto on_host_threads = [&](const std::function<void(int)>& f) {
+    const int nth = std::max(1, std::min(ns, (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    if (nth == 1) {
+      for (int s = 0; s < ns; ++s) f(s);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        for (int s = t; s < ns; s += nth) f(s);
+      });
+    for (auto& x : th) x.join();
+  };
+  auto run_propagate = [&]() {
+    if (!prop_pending) return;
+    prop_pending = false;
+    auto tg = clk::now();
+    const int p = p3, qout = 2 * m;
+    on_host_threads([&](int sd) {
+      const double* c = hC.data() + (size_t)sd * p * qout;
+      std::vector<double> tmp((size_t)p * qout);
+      for (int which = 0; which < 2; ++which) {
+        const double* g = (which ? hSB : hSA).data() + (size_t)sd * p * p;
+        double* out = (which ? hGB : hGA).data() + (size_t)sd * p3 * p3;
+        std::fill(out, out + (size_t)p3 * p3, 0.0);
+        for (int i = 0; i < p; ++i) {            // tmp = G C
+          double* ti = tmp.data() + (size_t)i * qout;
+          std::fill(ti, ti + qout, 0.0);
+          for (int k = 0; k < p; ++k) {
+            const double gik = g[(size_t)i * p + k];
+            if (gik == 0.0) continue;
+            const double* ck = c + (size_t)k * qout;
+            for (int j = 0; j < qout; ++j) ti[j] += gik * ck[j];
+          }
+        }
+        for (int k = 0; k < p; ++k) {            // out[0:qout, 0:qout] = C^T tmp
+          const double* ck = c + (size_t)k * qout;
+          const double* tk = tmp.data() + (size_t)k * qout;
+          for (int a = 0; a < qout; ++a) {
+            const double cka = ck[a];
+            if (cka == 0.0) continue;
+            double* oa = out + (size_t)a * p3;
+            for (int b = 0; b < qout; ++b) oa[b] += cka * tk[b];
+          }
+        }
+      }
+    });
+    t_prop_host += secs(tg, clk::now());
+  };
   auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
     auto tg1 = clk::now();
     std::fill(hC.begin(), hC.end(), 0.0);
+    const bool want_prop = (p == p3) && conv_sinvert_now;
     auto rr_one = [&](int s) {
       std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
       std::vector<double> gb(hGB.begin() + (size_t)s * p * p, hGB.begin() + (size_t)(s + 1) * p * p);
@@ -1212,42 +1271,13 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
           ga[a * p + b] = ga[b * p + a] = 0.5 * (ga[a * p + b] + ga[b * p + a]);
           gb[a * p + b] = gb[b * p + a] = 0.5 * (gb[a * p + b] + gb[b * p + a]);
         }
+      if (want_prop) {
+        std::copy(ga.begin(), ga.end(), hSA.begin() + (size_t)s * p * p);
+        std::copy(gb.begin(), gb.end(), hSB.begin() + (size_t)s * p * p);
+      }
       double* cs = hC.data() + (size_t)s * p * qout;
-      // The Gram blocks of the NEW [X P] follow from the old ones: [X' P'] = S C  =>  [X' P']^T A [X' P'] = C^T G_A C.
-      // Only the W rows of the next Gram matrices then need the GPU (a third of the flops, 5 block passes instead of
-      // 12); the explicit 96 x 96 products come back every `refresh` iterations together with the explicit A X, B X.
-      auto propagate = [&](int sd, const std::vector<double>& g_a, const std::vector<double>& g_b, const double* c) {
-        if (p != p3) return;
-        std::vector<double> tmp((size_t)p * qout);
-        for (int which = 0; which < 2; ++which) {
-          const std::vector<double>& g = which ? g_b : g_a;
-          double* out = (which ? hGBn : hGAn).data() + (size_t)sd * p3 * p3;
-          std::fill(out, out + (size_t)p3 * p3, 0.0);
-          for (int i = 0; i < p; ++i) {            // tmp = G C
-            double* ti = tmp.data() + (size_t)i * qout;
-            std::fill(ti, ti + qout, 0.0);
-            for (int k = 0; k < p; ++k) {
-              const double gik = g[(size_t)i * p + k];
-              if (gik == 0.0) continue;
-              const double* ck = c + (size_t)k * qout;
-              for (int j = 0; j < qout; ++j) ti[j] += gik * ck[j];
-            }
-          }
-          for (int k = 0; k < p; ++k) {            // out[0:qout, 0:qout] = C^T tmp
-            const double* ck = c + (size_t)k * qout;
-            const double* tk = tmp.data() + (size_t)k * qout;
-            for (int a = 0; a < qout; ++a) {
-              const double cka = ck[a];
-              if (cka == 0.0) continue;
-              double* oa = out + (size_t)a * p3;
-              for (int b = 0; b < qout; ++b) oa[b] += cka * tk[b];
-            }
-          }
-        }
-      };
       if (frozen[s]) {  // converged subdomain: keep X, drop P (identity update)
         for (int j = 0; j < m; ++j) cs[(size_t)j * qout + j] = 1.0;
-        propagate(s, ga, gb, cs);
         return;
       }
       std::vector<double> th, C;
@@ -1264,25 +1294,11 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
           lam[(size_t)s * m + j] = 1e300;  // fewer independent directions than m
         }
       }
-      propagate(s, ga, gb, cs);
     };
-    {  // the per-subdomain projected problems are independent: one host thread each (bounded)
-      const int nth = std::max(1, std::min(ns, (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
-      if (nth == 1) {
-        for (int s = 0; s < ns; ++s) rr_one(s);
-      } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nth; ++t)
-          th.emplace_back([&, t]() {
-            for (int s = t; s < ns; s += nth) rr_one(s);
-          });
-        for (auto& x : th) x.join();
-      }
-    }
-    if (p == p3) {
-      hGA.swap(hGAn);
-      hGB.swap(hGBn);
-      have_prop = true;      // hGA / hGB now hold the [X P] blocks of the new basis; the W rows are still to come
+    on_host_threads(rr_one);   // the per-subdomain projected problems are independent: one host thread each (bounded)
+    if (want_prop) {
+      prop_pending = true;   // hGA / hGB will hold the [X P] blocks of the new basis once run_propagate has run
+      have_prop = true;
     }
     t_rr_host += secs(tg1, clk::now());
     bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
@@ -1321,6 +1337,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   //   "residual": || r ||_2 <= tol (||A x||_2 + |lambda| ||B x||_2) (round 1; kept for the Chebyshev preconditioner,
   //   which is no approximation of A^-1 on the smooth components, and for checks of B with A = identity).
   const bool conv_sinvert = P.amg && opt.eps_conv != "residual";
+  conv_sinvert_now = conv_sinvert;
   fused_update = conv_sinvert && m == 32 && bk::lobpcg_update32_available() && !getenv("GENEO_LOBPCG_NO_FUSED_UPDATE");
   int it = 0;
   bool all_done = false;
@@ -1491,6 +1508,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       } else {
         device_phase();
       }
+      if (reduced) run_propagate();          // host work hidden behind the launches above
+      else prop_pending = false;             // the explicit 96 x 96 blocks are on their way
       auto tg0 = clk::now();
       if (reduced) {
         for (int which = 0; which < 2; ++which) {
@@ -1541,8 +1560,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
   bk::sync();
   if (getenv("GENEO_DEBUG"))
-    fprintf(stderr, "[lobpcg %s] %d iterations %.3f s: host Rayleigh-Ritz %.3f s, waiting for the Gram blocks %.3f s\n", P.label, it,
-            secs(t_lob0, clk::now()), t_rr_host, t_dev_wait);
+    fprintf(stderr, "[lobpcg %s] %d iterations %.3f s: host Rayleigh-Ritz %.3f s (+ %.3f s of Gram propagation behind the device phase), waiting for the Gram blocks %.3f s\n", P.label, it,
+            secs(t_lob0, clk::now()), t_rr_host, t_prop_host, t_dev_wait);
   cleanup();
   if (!all_done) {
     // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).

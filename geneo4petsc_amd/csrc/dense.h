@@ -162,6 +162,17 @@ inline void lu_solve(const std::vector<double>& a, int n, const std::vector<int>
   }
 }
 
+// sum a[k] b[k] with eight independent partial sums in a fixed order (vectorisable without re-association flags)
+inline double dot8(const double* a, const double* b, int n) {
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int k = 0;
+  for (; k + 8 <= n; k += 8)
+    for (int u = 0; u < 8; ++u) acc[u] += a[k + u] * b[k + u];
+  double s = 0.0;
+  for (; k < n; ++k) s += a[k] * b[k];
+  return s + ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+}
+
 // Symmetric eigen-decomposition A = V diag(w) V^T: Householder tridiagonalisation followed by the
 // implicit QL iteration (the classical tred2 / tql2 pair).  A is n x n row-major and is destroyed.
 // Eigenvalues ascending in w, eigenvectors in the COLUMNS of v (row-major n x n).
@@ -171,7 +182,7 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
   // and vectorisable; the eigenvectors are transposed back while sorting.
   v = a;
   w.assign(n, 0.0);
-  std::vector<double> e(n, 0.0);
+  std::vector<double> e(n, 0.0), rc(n, 0.0), rs(n, 0.0);
   auto V = [&](int i, int j) -> double& { return v[(size_t)j * n + i]; };
   if (n == 0) return;
   // ---- tred2
@@ -201,11 +212,9 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
       for (int j = 0; j < i; ++j) {
         f = w[j];
         V(j, i) = f;
-        g = e[j] + V(j, j) * f;
-        for (int k = j + 1; k <= i - 1; ++k) {
-          g += V(k, j) * w[k];
-          e[k] += V(k, j) * f;
-        }
+        const double* colj = v.data() + (size_t)j * n;      // V(k, j), contiguous in k
+        g = e[j] + colj[j] * f + dot8(colj + j + 1, w.data() + j + 1, i - 1 - j);
+        for (int k = j + 1; k <= i - 1; ++k) e[k] += colj[k] * f;
         e[j] = g;
       }
       f = 0.0;
@@ -232,9 +241,9 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
     if (h != 0.0) {
       for (int k = 0; k <= i; ++k) w[k] = V(k, i + 1) / h;
       for (int j = 0; j <= i; ++j) {
-        double g = 0.0;
-        for (int k = 0; k <= i; ++k) g += V(k, i + 1) * V(k, j);
-        for (int k = 0; k <= i; ++k) V(k, j) -= g * w[k];
+        double* colj = v.data() + (size_t)j * n;
+        const double g = dot8(v.data() + (size_t)(i + 1) * n, colj, i + 1);
+        for (int k = 0; k <= i; ++k) colj[k] -= g * w[k];
       }
     }
     for (int k = 0; k <= i; ++k) V(k, i + 1) = 0.0;
@@ -264,7 +273,7 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
         ++iter;
         double g = w[l];
         double p = (w[l + 1] - g) / (2.0 * e[l]);
-        double r = std::hypot(p, 1.0);
+        double r = std::sqrt(p * p + 1.0);
         if (p < 0) r = -r;
         w[l] = e[l] / (p + r);
         w[l + 1] = e[l] * (p + r);
@@ -276,23 +285,56 @@ inline void sym_eig(std::vector<double>& a, int n, std::vector<double>& w, std::
         double c = 1.0, c2 = c, c3 = c;
         const double el1 = e[l + 1];
         double s = 0.0, s2 = 0.0;
+        // The scalar recurrence of the sweep first (its chain of square roots and divisions is the critical path), the
+        // plane rotations of the eigenvector columns afterwards, a strip of rows at a time: the strip of column i + 1
+        // stays in registers while the sweep walks down the columns -- one load and one store per column and strip
+        // instead of two each, and the vector work no longer waits for the scalar chain.
         for (int i = m - 1; i >= l; --i) {
           c3 = c2;
           c2 = c;
           s2 = s;
           g = c * e[i];
           h = c * p;
-          r = std::hypot(p, e[i]);
+          r = std::sqrt(p * p + e[i] * e[i]);
           e[i + 1] = s * r;
           s = e[i] / r;
           c = p / r;
           p = c * w[i] - s * g;
           w[i + 1] = h + s * (c * g + s * w[i]);
-          for (int k = 0; k < n; ++k) {
-            h = V(k, i + 1);
-            V(k, i + 1) = s * V(k, i) + c * h;
-            V(k, i) = c * V(k, i) - s * h;
+          rc[i] = c;
+          rs[i] = s;
+        }
+        constexpr int STRIP = 16;
+        for (int k0 = 0; k0 < n; k0 += STRIP) {
+          const int kw = std::min(STRIP, n - k0);
+          double hh[STRIP];
+          const double* top = v.data() + (size_t)m * n + k0;
+          for (int k = 0; k < kw; ++k) hh[k] = top[k];
+          if (kw == STRIP) {
+            for (int i = m - 1; i >= l; --i) {
+              double* vi = v.data() + (size_t)i * n + k0;
+              double* vi1 = vi + n;
+              const double ci = rc[i], si = rs[i];
+              for (int k = 0; k < STRIP; ++k) {
+                const double x = vi[k];
+                vi1[k] = si * x + ci * hh[k];
+                hh[k] = ci * x - si * hh[k];
+              }
+            }
+          } else {
+            for (int i = m - 1; i >= l; --i) {
+              double* vi = v.data() + (size_t)i * n + k0;
+              double* vi1 = vi + n;
+              const double ci = rc[i], si = rs[i];
+              for (int k = 0; k < kw; ++k) {
+                const double x = vi[k];
+                vi1[k] = si * x + ci * hh[k];
+                hh[k] = ci * x - si * hh[k];
+              }
+            }
           }
+          double* bot = v.data() + (size_t)l * n + k0;
+          for (int k = 0; k < kw; ++k) bot[k] = hh[k];
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
         e[l] = s * p;

@@ -6,6 +6,7 @@
 #   bench [bench.py args]      one bench.py run, JSON line to gpurun_out/<tag>_bench.json
 #   debug [bench.py args]      the same with GENEO_DEBUG=1 (set-up / LOBPCG / AMG phase lines on stderr)
 #   prof  [bench.py args]      rocprofv3 --kernel-trace --stats of bench.py, per-kernel CSV to gpurun_out/<tag>_stats.csv
+#   trace <anchor> <occ> <cnt> [bench.py args]  kernel timeline window of bench.py (gaps between kernels)
 #   spmm  "<wpx list>" [args]  scripts/spmm_bench.py for each GENEO_SPMM_WPX in the list
 #   pmc   <counter> <cmd...>   rocprofv3 --pmc <counter> (own pass, kernel trace only) of a python command
 set -o pipefail
@@ -44,6 +45,13 @@ PY
     f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && cp $f $O/${TAG}_stats.csv && head -25 $O/${TAG}_stats.csv | cut -c1-200
     tail -2 $O/${TAG}_prof.err; exit $rc ;;
+  trace)  # kernel timeline of a window: trace <anchor kernel> <occurrence> <count> [bench.py args]
+    anchor=$1; occ=$2; cnt=$3; shift 3
+    rm -rf /tmp/trace_$TAG
+    (cd /tmp && timeout -k 10 ${LIMIT:-600} rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$TAG -o run -- python3 $R/bench.py "$@" > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err); rc=$?
+    f=$(find /tmp/trace_$TAG -name "*kernel_trace.csv" | head -1)
+    [ -n "$f" ] && python3 scripts/trace_window.py $f "$anchor" $occ $cnt > $O/${TAG}_window.txt && tail -3 $O/${TAG}_window.txt
+    exit $rc ;;
   spmm)
     list=$1; shift
     for w in $list; do

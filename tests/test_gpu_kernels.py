@@ -119,6 +119,40 @@ def test_fused_multigrid_epilogues(lib, m, density):
     np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
 
 
+@pytest.mark.parametrize("n,per_row", [(5000, 30), (8200, 22), (640, 45)])
+@pytest.mark.parametrize("m", [1, 16, 32])
+def test_wide_slice_kernels(lib, m, n, per_row):
+    """k_spmv_sell_wide / k_spmm_sell_wide (one workgroup per slice: coarse Galerkin operators and restrictions of
+    20-60 entries per row on more than 2^18 rows in production): plain product, row/column scalings and the four
+    multigrid epilogues.  Kind 101 keeps small ragged matrices on the slices instead of the lanes-per-row kernel."""
+    from geneo4petsc_amd.pc import Spmv
+    a = _rand_csr(n, per_row / n, 21)
+    assert np.diff(a.indptr).max() <= 64 and a.nnz >= 16 * n
+    rng = np.random.default_rng(22)
+    shape = (n,) if m == 1 else (n, m)
+    X, B, Z = rng.random(shape) - 0.5, rng.random(shape) - 0.5, rng.random(shape) - 0.5
+    dinv, w = rng.random(n) + 0.5, 0.61
+    d = dinv if m == 1 else dinv[:, None]
+    tol = dict(rtol=1e-12, atol=1e-13)
+    lib.GeneoSetSpmvKind(101)
+    try:
+        h = Spmv(a, lib)
+        if m == 1:
+            np.testing.assert_allclose(h.apply(X), a @ X, **tol)
+        else:
+            pre, post = rng.random(n) + 0.5, rng.random(n) + 0.5
+            np.testing.assert_allclose(h.spmm(X), a @ X, **tol)
+            np.testing.assert_allclose(h.spmm(X, pre, post), post[:, None] * (a @ (pre[:, None] * X)), **tol)
+        np.testing.assert_allclose(h.fused(1, X=X, B=B)[0], B - a @ X, **tol)
+        np.testing.assert_allclose(h.fused(2, X=X, Z=Z)[0], Z + a @ X, **tol)
+        np.testing.assert_allclose(h.fused(3, X=X, B=B, dinv=dinv, w=w)[0], X + w * d * (B - a @ X), **tol)
+        y, z = h.fused(4, B=B, dinv=dinv, w=w)
+        np.testing.assert_allclose(z, w * d * B, **tol)
+        np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
+    finally:
+        lib.GeneoSetSpmvKind(1)
+
+
 @pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 48), (96, 96), (64, 32), (192, 192), (20, 12)])
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_gram(lib, p, q, mfma):
