@@ -123,6 +123,8 @@ SYMBOLS = {
                       C.c_int, c_dbl_p]),
     "GeneoSpmmFused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_double]),
+    "GeneoSpmvFusedSingle": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_double]),
     "GeneoTestLobpcgUpdate": (C.c_int, [C.c_int, c_int_p] + [c_dbl_p] * 11),
     "GeneoBlockKernel": (C.c_int, [C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p,
                                    C.c_int, c_dbl_p]),

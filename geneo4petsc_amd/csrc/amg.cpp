@@ -368,6 +368,7 @@ void AmgDevice::free_all() {
   for (auto& L : lv) {
     bk::csr_free(L.Acs);
     if (L.own_A) bk::csr_free(L.A);
+    else bk::csr_free_lp(L.A);    // the companion of a borrowed matrix is ours
     bk::csr_free(L.P);
     bk::csr_free(L.R);
     bk::dfree(L.dinv); bk::dfree(L.b); bk::dfree(L.x); bk::dfree(L.r); bk::dfree(L.d); bk::dfree(L.ad);
@@ -418,6 +419,23 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
   bk::h2d(d_inv, coarse_inv.data(), sizeof(double) * coarse_inv.size());
   d_invbase = (int64_t*)bk::alloc(sizeof(int64_t) * coarse_base.size());
   bk::h2d(d_invbase, coarse_base.data(), sizeof(int64_t) * coarse_base.size());
+  if (prm.single) make_single();
+}
+
+// Single-precision companions (float values, 16-bit column offsets per slice: 6 bytes per entry instead of 12) of every
+// level matrix on the sliced path.  Only the single-vector V-cycle reads them -- the preconditioner of the FP64 PCG of
+// the local solves, whose passes over the fine and first coarse matrices are HBM streams; its arithmetic and its
+// vectors stay FP64, and so do the block cycles of LOBPCG (their traffic is the vector blocks, not the matrix).
+void AmgDevice::make_single() {
+  nlp = 0;
+  for (Lvl& L : lv) {
+    if (!L.fused) continue;
+    // the level-0 matrix may be borrowed: the companion then hangs off OUR copy of the descriptor
+    if (bk::csr_make_lp(L.A)) ++nlp;
+    if (L.Acs.n && bk::csr_make_lp(L.Acs, &L.A)) ++nlp;
+    if (L.P.n && bk::csr_make_lp(L.P)) ++nlp;
+    if (L.R.n && bk::csr_make_lp(L.R)) ++nlp;
+  }
 }
 
 void AmgDevice::make_column_scaled(Lvl& L) {
@@ -555,6 +573,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     so = csub;
   }
   opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;
+  if (prm.single) make_single();
   return true;
 }
 
@@ -605,11 +624,17 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
     // damped-Jacobi V-cycle in 4 launches per level: the vector passes ride on the SpMV / SpMM epilogues
     const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
     const double w = 1.0 / (0.5 * (lmax + lmin));
-    bk::spmm_fused(L.Acs.n ? L.Acs : L.A, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
-    applyA(L.R, L.r, m, C0.b, m, m);                                                      // restrict
+    const bk::Csr& Apre = L.Acs.n ? L.Acs : L.A;
+    const bool vec = (m == 1 && ldb <= 1 && ldx <= 1);     // contiguous single vectors: the companions apply
+    if (vec && bk::csr_has_lp(Apre)) bk::spmv_fused_lp(Apre, bk::EPI_PRE, nullptr, L.r, B, X, L.dinv, w);
+    else bk::spmm_fused(Apre, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
+    if (vec && bk::csr_has_lp(L.R)) bk::spmv_lp(L.R, L.r, C0.b);
+    else applyA(L.R, L.r, m, C0.b, m, m);                                                   // restrict
     cycle(l + 1, C0.b, m, C0.x, m, m);
-    bk::spmm_fused(L.P, bk::EPI_ADD, C0.x, m, L.d, m, m, nullptr, 0, X, ldx, nullptr, 0.0);  // t = x + P e
-    bk::spmm_fused(L.A, bk::EPI_JAC, L.d, m, X, ldx, m, B, ldb, nullptr, 0, L.dinv, w);   // x = t + w D^-1 (b - A t)
+    if (vec && bk::csr_has_lp(L.P)) bk::spmv_fused_lp(L.P, bk::EPI_ADD, C0.x, L.d, nullptr, X, nullptr, 0.0);
+    else bk::spmm_fused(L.P, bk::EPI_ADD, C0.x, m, L.d, m, m, nullptr, 0, X, ldx, nullptr, 0.0);  // t = x + P e
+    if (vec && bk::csr_has_lp(L.A)) bk::spmv_fused_lp(L.A, bk::EPI_JAC, L.d, X, B, nullptr, L.dinv, w);
+    else bk::spmm_fused(L.A, bk::EPI_JAC, L.d, m, X, ldx, m, B, ldb, nullptr, 0, L.dinv, w);   // x = t + w D^-1 (b - A t)
     return;
   }
   smooth(L, B, ldb, X, ldx, m, true);                                      // pre-smoothing, zero guess

@@ -18,6 +18,7 @@ struct AmgParams {
   int coarse_size = 600;      // stop coarsening when every subdomain block is at most this large
   int smooth_degree = 1;      // Chebyshev-Jacobi smoother degree (1 = damped Jacobi)
   double smooth_ratio = 4.0;  // smoothing interval [rho/ratio, 1.1 rho]
+  bool single = false;        // single-vector V-cycles read single-precision companions of the level matrices (FP64 arithmetic)
 };
 
 struct AmgLevelHost {
@@ -54,6 +55,7 @@ class AmgDevice {
   int nlevels() const { return (int)lv.size(); }
   double operator_complexity() const { return opc; }
   void free_all();
+  int lp_matrices() const { return nlp; }   // level matrices that carry a single-precision companion
 
  private:
   struct Lvl {
@@ -73,6 +75,8 @@ class AmgDevice {
   AmgParams prm;
   int maxm = 1;
   double opc = 1.0;
+  int nlp = 0;
+  void make_single();
   void alloc_level_buffers(Lvl& L, bool coarse);
   void make_column_scaled(Lvl& L);
   void applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m);

@@ -56,6 +56,13 @@ struct Csr {
   bool alias = false;          // values-only copy of another matrix (csr_scaled_alias): the index arrays are borrowed
   bool col_scaled = false;     // the values already carry the column scaling the EPI_PRE epilogue would apply (A diag(dinv))
   bool fine = false;           // a subdomain-level (fine) operator: its launches are the ones bench.py's in-situ timer samples
+  // single-precision companion of the sliced layout (preconditioner use only: the V-cycle of the local solves): values as
+  // float, columns as 16-bit offsets from the slice's lowest column, same sl_ptr -- 6 bytes per entry instead of 12.
+  // lp_col / lp_base stay null when a slice spans more than 65535 columns (the kernels then read sl_col: 8 bytes per
+  // entry); all three are null when the matrix is not on the sliced path.
+  float* lp_val = nullptr;
+  unsigned short* lp_col = nullptr;
+  int* lp_base = nullptr;      // nslice
   int vec_lpr = 0;             // > 0: long / ragged rows (restriction, coarse Galerkin operators): the SpMV runs the
                                // lanes-per-row CSR kernel with this many lanes per row instead of the slices
 };
@@ -101,6 +108,14 @@ void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, in
 //   EPI_JAC : Y = X + w dinv .* (B - A X)         (damped-Jacobi sweep, out of place)
 //   EPI_PRE : Z = w dinv .* B ;  Y = B - A Z      (zero-guess sweep + residual; X unused)
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_ADD = 2, EPI_JAC = 3, EPI_PRE = 4 };
+// Builds the single-precision companion (false: the matrix is not on the sliced path).  index_owner: the matrix a
+// values-only alias borrows its index arrays from (its companion must exist already).
+bool csr_make_lp(Csr& a, const Csr* index_owner = nullptr);
+void csr_free_lp(Csr& a);
+inline bool csr_has_lp(const Csr& a) { return a.lp_val != nullptr; }
+// y = A x / the fused epilogues of spmm_fused for ONE contiguous vector, reading the companion (FP64 arithmetic)
+void spmv_lp(const Csr& a, const double* x, double* y);
+void spmv_fused_lp(const Csr& a, int epi, const double* x, double* y, const double* b, double* z, const double* dinv, double w);
 bool csr_fusable(const Csr& a);   // no long-row remainder and the sliced layout is in use
 void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
                 double* Z, int ldz, const double* dinv, double w);

@@ -246,7 +246,15 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
     len = rowptr[i + 1] - a;
   }
   const bool use = (i < n) && len <= long_len;
-  const int padc = (i < n && len > 0) ? col[a] : 0;
+  // padding entries (value 0) point at a column NEAR the slice's own -- the row's first one, or for an empty row / the
+  // rows past the end of the last slice the entry just before: the x gathers stay local and the slice's column span
+  // (16-bit offsets of the single-precision companion) is not widened by the padding
+  int padc = 0;
+  if (i < n && len > 0) padc = col[a];
+  else if (n > 0 && rowptr[n] > 0) {
+    const int k = (i < n) ? a : rowptr[n];
+    padc = col[k > 0 ? k - 1 : 0];
+  }
   for (int k = 0; k < w; ++k) {
     const int64_t e = base + (int64_t)64 * k + l;
     if (use && k < len) {
@@ -720,7 +728,13 @@ void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, do
                      dinv_dev, w);
 }
 
+void csr_free_lp(Csr& a) {
+  dfree(a.lp_val);
+  if (!a.alias) { dfree(a.lp_col); dfree(a.lp_base); }
+  a.lp_val = nullptr; a.lp_col = nullptr; a.lp_base = nullptr;
+}
 void csr_free(Csr& a) {
+  csr_free_lp(a);
   if (a.alias) {   // values-only copy: the index arrays belong to the matrix it was made from
     dfree(a.val); dfree(a.sl_val);
     a = Csr();
@@ -753,6 +767,7 @@ __global__ __launch_bounds__(256) void k_scale_sell(int n, int ns, const int64_t
 Csr csr_scaled_alias(const Csr& a, const double* row_scale, const double* col_scale, bool col_is_dinv) {
   Csr b = a;
   b.alias = true;
+  b.lp_val = nullptr; b.lp_col = nullptr; b.lp_base = nullptr;
   b.col_scaled = col_is_dinv;
   b.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
   b.sl_val = (double*)alloc(sizeof(double) * (size_t)std::max<int64_t>(1, a.sl_nnz));
@@ -975,6 +990,170 @@ static void spmv_wide_launch(const Csr& a, const double* x, double* y, const dou
   hipLaunchKernelGGL((k_spmv_sell_wide<EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, a.sl_col,
                      a.sl_val, x, y, b, z, dinv, w, a.col_scaled ? (const double*)nullptr : dinv);
 }
+// ------------------------------------------------------------------------------- single-precision companion
+// (col, val) of the slices at 6 bytes per entry for the V-cycle of the local solves: the preconditioner of an FP64 PCG
+// needs its operator to a few digits only, and its passes over the fine and first coarse matrices are pure HBM streams.
+// Arithmetic stays FP64 (values are widened on load), vectors stay FP64.
+__global__ __launch_bounds__(256) void k_lp_base(int ns, const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
+                                                 int* __restrict__ base, int* __restrict__ fail) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= ns) return;
+  const int l = threadIdx.x & 63;
+  int lo = 0x7fffffff, hi = 0;
+  for (int64_t e = sl_ptr[s] + l; e < sl_ptr[s + 1]; e += 64) {
+    const int c = sl_col[e];
+    lo = c < lo ? c : lo;
+    hi = c > hi ? c : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int lo2 = __shfl_xor(lo, o, 64), hi2 = __shfl_xor(hi, o, 64);
+    lo = lo2 < lo ? lo2 : lo;
+    hi = hi2 > hi ? hi2 : hi;
+  }
+  if (l == 0) {
+    if (lo == 0x7fffffff) lo = 0;          // empty slice
+    base[s] = lo;
+    if (hi - lo > 65535) atomicExch(fail, 1);
+  }
+}
+__global__ __launch_bounds__(256) void k_lp_fill(int ns, const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
+                                                 const double* __restrict__ sl_val, const int* __restrict__ base,
+                                                 unsigned short* __restrict__ c16, float* __restrict__ v32) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= ns) return;
+  const int l = threadIdx.x & 63;
+  const int b = c16 ? base[s] : 0;
+  for (int64_t e = sl_ptr[s] + l; e < sl_ptr[s + 1]; e += 64) {
+    if (c16) c16[e] = (unsigned short)(sl_col[e] - b);
+    v32[e] = (float)sl_val[e];
+  }
+}
+bool csr_make_lp(Csr& a, const Csr* index_owner) {
+  if (spmv_kind() != 1 || a.nslice == 0 || !a.sl_ptr || a.vec_lpr > 0 || a.nlong > 0 || a.lp_val) return a.lp_val != nullptr;
+  if (index_owner) {
+    if (!index_owner->lp_val || index_owner->sl_col != a.sl_col) return false;
+    a.lp_col = index_owner->lp_col;
+    a.lp_base = index_owner->lp_base;
+  } else {
+    a.lp_base = (int*)alloc(sizeof(int) * (size_t)a.nslice);
+    int* dfail = (int*)alloc(sizeof(int));
+    HIPCHK(hipMemsetAsync(dfail, 0, sizeof(int), g_stream));
+    hipLaunchKernelGGL(k_lp_base, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.nslice, a.sl_ptr, a.sl_col, a.lp_base,
+                       dfail);
+    int hfail = 0;
+    d2h(&hfail, dfail, sizeof(int));
+    dfree(dfail);
+    if (hfail) {             // a slice spans more than 65535 columns: float values over the 32-bit columns (8 B per entry)
+      dfree(a.lp_base);
+      a.lp_base = nullptr;
+    } else {
+      a.lp_col = (unsigned short*)alloc(sizeof(unsigned short) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+    }
+  }
+  a.lp_val = (float*)alloc(sizeof(float) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+  hipLaunchKernelGGL(k_lp_fill, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.nslice, a.sl_ptr, a.sl_col, a.sl_val,
+                     a.lp_base, (index_owner || !a.lp_col) ? (unsigned short*)nullptr : a.lp_col, a.lp_val);
+  return true;
+}
+// WPS = 1: one wave per slice (four slices per workgroup), WPS = 4: one workgroup per slice (wide slices), as the FP64
+// kernels k_spmv_sell_epi / k_spmv_sell_wide above; summation order fixed.
+template <int EPI, int WPS, typename COLT>
+__global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict__ sl_ptr, int nslice, int n,
+                                                      const COLT* __restrict__ col, const float* __restrict__ val,
+                                                      const int* __restrict__ base, const double* __restrict__ x,
+                                                      double* __restrict__ y, const double* __restrict__ b,
+                                                      double* __restrict__ z, const double* __restrict__ dinv, double w,
+                                                      const double* __restrict__ cs) {
+  constexpr int UNR = 4;
+  __shared__ double part[3][64];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int s;
+  if (WPS == 1) {
+    const int nwb = (nslice + 3) >> 2;
+    const int t = xcd_remap(blockIdx.x, nwb);
+    s = 4 * t + wv;
+    if (t >= nwb || s >= nslice) return;
+  } else {
+    s = xcd_remap(blockIdx.x, nslice);
+    if (s >= nslice) return;
+  }
+  const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
+  const int cb = base ? base[s] : 0;     // 16-bit columns are offsets from the slice's lowest column
+  const double* __restrict__ xin = (EPI == EPI_PRE) ? b : x;
+  constexpr int STEP = 64 * WPS;
+  double acc[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
+  int64_t e = a + (WPS == 1 ? 0 : 64 * wv) + l;
+  for (; e + STEP * (UNR - 1) < e1; e += STEP * UNR) {
+    int c[UNR];
+    double v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      c[u] = cb + (int)col[e + STEP * u];
+      v[u] = (double)val[e + STEP * u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc[u] += v[u] * ((EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]]);
+  }
+  for (; e < e1; e += STEP) {
+    const int c0 = cb + (int)col[e];
+    acc[0] += (double)val[e] * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
+  }
+  double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (WPS == 4) {
+    if (wv > 0) part[wv - 1][l] = sum;
+    __syncthreads();
+    if (wv > 0) return;
+    sum = (sum + part[0][l]) + (part[1][l] + part[2][l]);
+  }
+  const int r = 64 * s + l;
+  if (r >= n) return;
+  if (EPI == EPI_NONE) {
+    y[r] = sum;
+  } else if (EPI == EPI_RES) {
+    y[r] = b[r] - sum;
+  } else if (EPI == EPI_ADD) {
+    y[r] = z[r] + sum;
+  } else if (EPI == EPI_JAC) {
+    y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else {  // EPI_PRE
+    const double bb = b[r];
+    z[r] = w * dinv[r] * bb;
+    y[r] = bb - w * sum;
+  }
+}
+template <int EPI>
+static void spmv_lp_launch(const Csr& a, const double* x, double* y, const double* b, double* z, const double* dinv, double w) {
+  if (!a.lp_val) throw std::runtime_error("spmv_lp: the matrix has no single-precision companion");
+  if (a.n == 0) return;
+  const double* cs = (EPI == EPI_PRE && !a.col_scaled) ? dinv : nullptr;
+  const int per = (a.nslice + 7) / 8;
+  const int perw = ((a.nslice + 3) / 4 + 7) / 8;
+#define LP_LAUNCH(WPS, COLT, colp, grid)                                                                              \
+  hipLaunchKernelGGL((k_spmv_sell_lp<EPI, WPS, COLT>), dim3(grid), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, colp, \
+                     a.lp_val, a.lp_base, x, y, b, z, dinv, w, cs)
+  if (sell_wide(a)) {
+    if (a.lp_col) LP_LAUNCH(4, unsigned short, a.lp_col, per * 8);
+    else LP_LAUNCH(4, int, a.sl_col, per * 8);
+  } else {
+    if (a.lp_col) LP_LAUNCH(1, unsigned short, a.lp_col, perw * 8);
+    else LP_LAUNCH(1, int, a.sl_col, perw * 8);
+  }
+#undef LP_LAUNCH
+}
+void spmv_lp(const Csr& a, const double* x, double* y) { spmv_lp_launch<EPI_NONE>(a, x, y, nullptr, nullptr, nullptr, 0.0); }
+void spmv_fused_lp(const Csr& a, int epi, const double* x, double* y, const double* b, double* z, const double* dinv, double w) {
+  switch (epi) {
+    case EPI_RES: spmv_lp_launch<EPI_RES>(a, x, y, b, z, dinv, w); break;
+    case EPI_ADD: spmv_lp_launch<EPI_ADD>(a, x, y, b, z, dinv, w); break;
+    case EPI_JAC: spmv_lp_launch<EPI_JAC>(a, x, y, b, z, dinv, w); break;
+    case EPI_PRE: spmv_lp_launch<EPI_PRE>(a, x, y, b, z, dinv, w); break;
+    default: throw std::runtime_error("spmv_fused_lp: unknown epilogue");
+  }
+}
+
 // Lanes-per-row CSR kernel for long / ragged rows, with the same epilogues: LPR lanes stride over one row
 // (coalesced col/val reads), partial sums are combined by a fixed butterfly, lane 0 writes.
 template <int LPR, int EPI>

@@ -157,6 +157,7 @@ const char* usageGenEO_c(void) {
          "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_pc_type amg|cheb\n"
          "  -els2_cheb_degree / -els2_cheb_ratio\n"
          "  -dls1_ksp_rtol / -dls1_ksp_max_it / -dls1_pc_type amg|jacobi   local solves (batched PCG)\n"
+         "  -dls1_amg_precision single|double   storage of the matrices its V-cycle reads (arithmetic and vectors: double)\n"
          "  -amg_coarse_size / -amg_smooth_degree / -amg_smooth_ratio / -amg_max_levels\n"
          "  -ksp_type cg|gmres -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart\n\n";
 }
@@ -603,6 +604,19 @@ PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X, double* Y, 
   if (!h) return 1;
   GUARD_BEGIN
   bk::spmm_fused(h->a, epi, X, m, Y, m, m, B, m, Z, m, dinv, w);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+
+// the same single-vector launches reading the single-precision companion of the matrix (built on first use); epi 0: Y = A X
+PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X, double* Y, const double* B, double* Z,
+                                    const double* dinv, double w) {
+  if (!h) return 1;
+  GUARD_BEGIN
+  if (!bk::csr_has_lp(h->a) && !bk::csr_make_lp(h->a))
+    throw std::runtime_error("no single-precision companion for this matrix (ragged or long rows: not on the sliced path)");
+  if (epi == 0) bk::spmv_lp(h->a, X, Y);
+  else bk::spmv_fused_lp(h->a, epi, X, Y, B, Z, dinv, w);
   GUARD_END((PC) nullptr)
   return 0;
 }

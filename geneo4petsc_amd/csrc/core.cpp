@@ -142,6 +142,11 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
     o.els2_pc = value;
     return "";
   }
+  if (key == "-dls1_amg_precision") {
+    if (value != "single" && value != "double") return "unsupported -dls1_amg_precision " + value;
+    o.dls1_amg_single = (value == "single");
+    return "";
+  }
   if (key == "-amg_coarse_size") return integer(o.amg_coarse_size);
   if (key == "-amg_smooth_degree") return integer(o.amg_smooth_degree);
   if (key == "-amg_smooth_ratio") return dbl(o.amg_smooth_ratio);
@@ -490,10 +495,13 @@ int PC::finish_amg1() {
   try {
     amg1 = new AmgDevice();
     // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
-    amg1->upload(p->res.levels, p->res.cinv, p->res.cbase, amg_params(opt),
+    AmgParams ap1 = amg_params(opt);
+    ap1.single = opt.dls1_amg_single;
+    amg1->upload(p->res.levels, p->res.cinv, p->res.cbase, ap1,
                  (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
     info.amg_levels = amg1->nlevels();
     info.amg_operator_complexity = amg1->operator_complexity();
+    if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] level-1 hierarchy: %d matrices with a single-precision companion\n", amg1->lp_matrices());
   } catch (std::exception& e) {
     return fail(e.what());
   }

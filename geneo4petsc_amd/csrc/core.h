@@ -46,6 +46,7 @@ struct Options {
   std::string dls1_pc = "amg", els2_pc = "amg";
   int amg_coarse_size = 600, amg_smooth_degree = 1, amg_max_levels = 10;
   double amg_smooth_ratio = 4.0;
+  bool dls1_amg_single = true;   // -dls1_amg_precision single|double: storage of the level matrices the V-cycle of the local solves reads
   // Krylov driver (counterpart of the PETSc KSP the reference calls at driver:1240)
   std::string ksp_type = "gmres";
   double ksp_rtol = 1e-5, ksp_atol = 1e-50, ksp_dtol = 1e5;

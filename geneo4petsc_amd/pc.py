@@ -378,6 +378,17 @@ class Spmv:
         shape = (self.n,) if ref.ndim == 1 else (self.n, m)
         return yd.to_host().reshape(shape), (zd.to_host().reshape(shape) if zd is not None else None)
 
+    def fused_single(self, epi, X=None, B=None, Z=None, dinv=None, w=0.0):
+        """The single-vector launches of `fused` (epi 0: A X) on the single-precision companion of the matrix."""
+        dev = lambda a: DeviceVector.from_host(self.lib, np.ascontiguousarray(a, dtype=np.float64).ravel()) if a is not None else None
+        xd, bd, dd = dev(X), dev(B), dev(dinv)
+        zd = dev(Z) if Z is not None else (DeviceVector(self.lib, self.n) if epi == 4 else None)
+        yd = DeviceVector(self.lib, self.n)
+        p = lambda v: v.ptr if v is not None else None
+        if self.lib.GeneoSpmvFusedSingle(self.h, int(epi), p(xd), yd.ptr, p(bd), p(zd), p(dd), float(w)):
+            raise GenEOError(self.lib.PCGenEOGetError(None).decode())
+        return yd.to_host(), (zd.to_host() if zd is not None else None)
+
     def algorithmic_bytes(self):
         """nnz*(8+4) + (n+1)*4 + n*8 (x once) + n*8 (y)."""
         return self.nnz * 12 + (self.n + 1) * 4 + self.n * 16

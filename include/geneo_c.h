@@ -258,6 +258,11 @@ PetscErrorCode GeneoSpmmTime(GeneoSpmv h, const double* X_dev, int ldx, double* 
  *   epi 1: Y = B - A X      2: Y = Z + A X      3: Y = X + w dinv.*(B - A X)      4: Z = w dinv.*B, Y = B - A Z */
 PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, int m, const double* B_dev,
                               double* Z_dev, const double* dinv_dev, double w);
+/* the single-vector launches (m = 1; epi 0: Y = A X) reading the matrix's single-precision companion -- float values,
+ * 16-bit column offsets per 64-row slice (32-bit columns when a slice spans more than 65535), FP64 arithmetic: what the V-cycle of the local solves streams
+ * (-dls1_amg_precision single).  Error when the matrix has no such companion. */
+PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, const double* B_dev,
+                                    double* Z_dev, const double* dinv_dev, double w);
 /* device sparse products of the multigrid set-up (test hook): op 0: C = A B, op 1: C = A^T; returns nnz(C), -1 when a
  * row exceeds the kernels' per-row capacity (callers fall back to the host product), -2 on error */
 long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, int ncols, int* rowptr_out, int* col_out,

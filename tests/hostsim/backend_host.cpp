@@ -110,6 +110,13 @@ Csr csr_scaled_alias(const Csr& a, const double* rs, const double* cs, bool col_
     for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) b.val[k] = (rs ? rs[r] : 1.0) * a.val[k] * (cs ? cs[a.col[k]] : 1.0);
   return b;
 }
+// no single-precision companions on the test backend: the V-cycle takes its FP64 path
+bool csr_make_lp(Csr&, const Csr*) { return false; }
+void csr_free_lp(Csr&) {}
+void spmv_lp(const Csr&, const double*, double*) { throw std::runtime_error("hostsim: no single-precision companion"); }
+void spmv_fused_lp(const Csr&, int, const double*, double*, const double*, double*, const double*, double) {
+  throw std::runtime_error("hostsim: no single-precision companion");
+}
 void spmv(const Csr& a, const double* x, double* y) {
   for (int i = 0; i < a.n; ++i) {
     double s = 0;

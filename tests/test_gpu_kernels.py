@@ -29,6 +29,19 @@ def _rand_csr(n, density, seed, long_row=None):
     return a
 
 
+def _band_csr(n, per_row, half_width, seed):
+    """random entries within `half_width` columns of the diagonal (what a locally numbered mesh operator looks like)"""
+    rng = np.random.default_rng(seed)
+    nnz = n * per_row
+    rows = rng.integers(0, n, size=nnz)
+    cols = np.clip(rows + rng.integers(-half_width, half_width + 1, size=nnz), 0, n - 1)
+    a = sp.csr_matrix((rng.random(nnz) - 0.5, (rows, cols)), shape=(n, n)) + sp.diags(rng.random(n) + 1.0)
+    a = a.tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    return a
+
+
 def test_backend_is_hip(lib):
     assert lib.GeneoBackendName() == b"hip-gfx950"
 
@@ -151,6 +164,46 @@ def test_wide_slice_kernels(lib, m, n, per_row):
         np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
     finally:
         lib.GeneoSetSpmvKind(1)
+
+
+@pytest.mark.parametrize("n,per_row,kind,half_width", [(5000, 8, 1, 20000), (300000, 6, 1, 20000), (300000, 6, 1, 150000),
+                                                       (5000, 30, 101, 2000), (640, 45, 101, 300)])
+def test_single_precision_companion(lib, n, per_row, kind, half_width):
+    """k_spmv_sell_lp (wave-per-slice and workgroup-per-slice forms): the product and the four epilogues against the
+    FP64 algebra on the matrix ROUNDED to float (the companion stores float values, arithmetic is FP64: agreement to
+    1e-12), and against the unrounded matrix to single precision."""
+    from geneo4petsc_amd.pc import Spmv
+    a = _band_csr(n, per_row, half_width, 31)
+    assert np.diff(a.indptr).max() <= 64
+    a32 = a.copy()
+    a32.data = a32.data.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(32)
+    X, B, Z = rng.random(n) - 0.5, rng.random(n) - 0.5, rng.random(n) - 0.5
+    dinv, w = rng.random(n) + 0.5, 0.61
+    tol = dict(rtol=1e-12, atol=1e-13)
+    lib.GeneoSetSpmvKind(kind)
+    try:
+        h = Spmv(a, lib)
+        y = h.fused_single(0, X=X)[0]
+        np.testing.assert_allclose(y, a32 @ X, **tol)
+        np.testing.assert_allclose(y, a @ X, rtol=0, atol=1e-6 * np.abs(a @ X).max())
+        np.testing.assert_allclose(h.fused_single(1, X=X, B=B)[0], B - a32 @ X, **tol)
+        np.testing.assert_allclose(h.fused_single(2, X=X, Z=Z)[0], Z + a32 @ X, **tol)
+        np.testing.assert_allclose(h.fused_single(3, X=X, B=B, dinv=dinv, w=w)[0], X + w * dinv * (B - a32 @ X), **tol)
+        y, z = h.fused_single(4, B=B, dinv=dinv, w=w)
+        np.testing.assert_allclose(z, w * dinv * B, **tol)
+        np.testing.assert_allclose(y, B - a32 @ (w * dinv * B), **tol)
+    finally:
+        lib.GeneoSetSpmvKind(1)
+
+
+def test_single_precision_companion_keeps_32bit_columns_for_wide_slices(lib):
+    """A slice whose columns span more than 65535 keeps its 32-bit columns (float values only)."""
+    from geneo4petsc_amd.pc import Spmv
+    n = 70000
+    a = (sp.diags(np.arange(1.0, n + 1)) + sp.csr_matrix((np.full(1, 0.25), ([0], [n - 1])), shape=(n, n))).tocsr()
+    x = np.random.default_rng(3).random(n)
+    np.testing.assert_allclose(Spmv(a, lib).fused_single(0, X=x)[0], a @ x, rtol=1e-12)
 
 
 @pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 48), (96, 96), (64, 32), (192, 192), (20, 12)])
