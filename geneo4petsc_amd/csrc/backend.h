@@ -153,7 +153,7 @@ struct Chunks {
   int* suboff = nullptr;   // nsub+1 : first row of each subdomain
   double* partial = nullptr;  // 4*nchunk scratch
 };
-Chunks chunks_upload(int nsub, const int* h_suboff /*nsub+1*/);
+Chunks chunks_upload(int nsub, const int* h_suboff /*nsub+1: absolute first rows, h_suboff[0] need not be 0*/);
 void   chunks_free(Chunks& c);
 // out[s*stride + slot] = sum over subdomain s of x.*y
 void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot);
@@ -177,6 +177,9 @@ void cg_direction(const Chunks& c, double* sc, int parity, double* p, const doub
 // ---- tall-skinny block kernels, per subdomain -----------------------------------------------
 // G[s] (p x q row-major at G + s*p*q) = S_s^T T_s
 void gram(const Chunks& c, const double* S, int lds, int p, const double* T, int ldt, int q, double* G);
+// G[s] ((p1 + p2) x q) = [S1 | S2]^T T: two left blocks that live in different buffers against ONE pass over T
+void gram2(const Chunks& c, const double* S1, int lds1, int p1, const double* S2, int lds2, int p2, const double* T, int ldt,
+           int q, double* G);
 // Y_s (+)= S_s C_s : S (n x p), C[s] (p x q row-major at C + s*p*q), Y (n x q)
 void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C, int q, double* Y, int ldy,
                bool accumulate);
@@ -240,6 +243,9 @@ const char* spmv_kernel_name();
 void  set_mfma(bool enable);   // false: run the plain-FMA twins of the MFMA kernels (validation)
 int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as the kernels assume
 void* event_create();
+// device-to-host copy on a side stream as soon as `event` (recorded on the library stream) has completed: the library
+// stream keeps running the launches queued behind the event
+void  d2h_after(void* host, const void* dev, size_t bytes, void* event);
 void  event_record(void* ev);
 float event_elapsed_ms(void* a, void* b);   // syncs on b
 void  event_destroy(void* ev);

@@ -1931,7 +1931,7 @@ void dot(const double* x, const double* y, int n, double* out_dev) {
 Chunks chunks_upload(int nsub, const int* h_suboff) {
   Chunks c;
   c.nsub = nsub;
-  c.n = h_suboff[nsub];
+  c.n = h_suboff[nsub] - h_suboff[0];
   std::vector<int> st, ln, sb, sp;
   sp.push_back(0);
   for (int s = 0; s < nsub; ++s) {
@@ -2186,7 +2186,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                                                    const int* __restrict__ gfirst, const int* __restrict__ gcount,
                                                    const double* __restrict__ S, int lds_, int p,
                                                    const double* __restrict__ T, int ldt_, int q,
-                                                   double* __restrict__ Gpart, int I0, int J0) {
+                                                   double* __restrict__ Gpart, int I0, int J0,
+                                                   const double* __restrict__ S2, int lds2_, int psplit) {
+  // S2 != nullptr: the left operand is [S(:, 0:psplit) | S2(:, 0:p-psplit)] -- two blocks that live in different
+  // buffers (A W and B W) against ONE pass over T
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int ldS = (p % 32 == 0) ? p + 16 : p;  // rows r, r+1 land 32 banks apart
   const int ldT = (q % 32 == 0) ? q + 16 : q;
@@ -2225,11 +2228,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
       const int rr = r + 4 * w + u;
       const bool ok = rr < nrows;
       const double* srow = S + (int64_t)(row0 + (ok ? rr : 0)) * lds_;
+      const double* srow2 = S2 ? S2 + (int64_t)(row0 + (ok ? rr : 0)) * lds2_ - psplit : srow;
       const double* trow = T + (int64_t)(row0 + (ok ? rr : 0)) * ldt_;
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
         const int cc = l + 64 * ci;
-        rs[u][ci] = (ok && cc < p) ? srow[cc] : 0.0;
+        rs[u][ci] = (ok && cc < p) ? (cc < psplit ? srow[cc] : srow2[cc]) : 0.0;
         rt[u][ci] = (ok && cc < q) ? trow[cc] : 0.0;
       }
     }
@@ -2284,7 +2288,8 @@ __global__ __launch_bounds__(256) void k_gram_fma(const int* __restrict__ cstart
                                                   const int* __restrict__ gfirst, const int* __restrict__ gcount,
                                                   const double* __restrict__ S, int lds_, int p,
                                                   const double* __restrict__ T, int ldt_, int q,
-                                                  double* __restrict__ Gpart) {
+                                                  double* __restrict__ Gpart, const double* __restrict__ S2, int lds2_,
+                                                  int psplit) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sS = smem;           // 16 x p
   double* sT = smem + 16 * p;  // 16 x q
@@ -2304,7 +2309,8 @@ __global__ __launch_bounds__(256) void k_gram_fma(const int* __restrict__ cstart
     __syncthreads();
     for (int e = tid; e < 16 * p; e += 256) {
       const int rr = e / p, cc = e - rr * p;
-      sS[e] = (rr < nr) ? S[(int64_t)(row0 + r + rr) * lds_ + cc] : 0.0;
+      sS[e] = (rr < nr) ? (cc < psplit ? S[(int64_t)(row0 + r + rr) * lds_ + cc]
+                                       : S2[(int64_t)(row0 + r + rr) * lds2_ + cc - psplit]) : 0.0;
     }
     for (int e = tid; e < 16 * q; e += 256) {
       const int rr = e / q, cc = e - rr * q;
@@ -2392,7 +2398,8 @@ void gram_plan_drop(const Chunks& c) {
     }
 }
 
-void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, int ldt_, int q, double* G) {
+static void gram_impl(const Chunks& c, const double* S, int lds_, int p, const double* S2, int lds2_, int psplit,
+                      const double* T, int ldt_, int q, double* G) {
   if (c.nchunk == 0 || p == 0 || q == 0) return;
   ProfScope prof(PROF_GRAM, p >= 32 && q >= 32, 8.0 * (double)c.n * (p + q), 2.0 * (double)c.n * p * q);
   GramPlan& pl = gram_plan(c);
@@ -2414,10 +2421,10 @@ void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, in
   do {                                                                                                                \
     if (std::max(p, q) <= 128)                                                                                        \
       hipLaunchKernelGGL((k_gram_mfma<A, B, 2>), dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, \
-                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, I0, J0);                                         \
+                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, I0, J0, S2, lds2_, psplit);                      \
     else                                                                                                              \
       hipLaunchKernelGGL((k_gram_mfma<A, B, 3>), dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, \
-                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, I0, J0);                                         \
+                         pl.gcount, S, lds_, p, T, ldt_, q, pl.part, I0, J0, S2, lds2_, psplit);                      \
   } while (0)
         switch (ti * 10 + tj) {
           case 11: GRAM_LAUNCH(1, 1); break;
@@ -2436,10 +2443,17 @@ void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, in
     if ((size_t)p * q > 256 * 40) throw std::runtime_error("gram: p*q too large for the FMA kernel");
     const size_t sm = sizeof(double) * 16 * (size_t)(p + q);
     hipLaunchKernelGGL(k_gram_fma, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, pl.gcount,
-                       S, lds_, p, T, ldt_, q, pl.part);
+                       S, lds_, p, T, ldt_, q, pl.part, S2 ? S2 : S, lds2_, psplit);
   }
   hipLaunchKernelGGL(k_gram_reduce, dim3(grid1d(p * q, 64), c.nsub), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
                      p * q, G);
+}
+void gram(const Chunks& c, const double* S, int lds_, int p, const double* T, int ldt_, int q, double* G) {
+  gram_impl(c, S, lds_, p, nullptr, 0, p, T, ldt_, q, G);
+}
+void gram2(const Chunks& c, const double* S1, int lds1, int p1, const double* S2, int lds2, int p2, const double* T,
+           int ldt_, int q, double* G) {
+  gram_impl(c, S1, lds1, p1 + p2, S2, lds2, p1, T, ldt_, q, G);
 }
 
 // Y[rows] (+)= S[rows] C_s : one workgroup per chunk, 64-row slabs of S through LDS, the wave's
@@ -3143,6 +3157,14 @@ void* event_create() {
   return (void*)e;
 }
 void event_record(void* ev) { HIPCHK(hipEventRecord((hipEvent_t)ev, g_stream)); }
+static hipStream_t g_copy_stream = nullptr;
+void d2h_after(void* host, const void* dev, size_t bytes, void* event) {
+  if (!bytes) return;
+  if (!g_copy_stream) HIPCHK(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamWaitEvent(g_copy_stream, (hipEvent_t)event, 0));
+  HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, g_copy_stream));
+  HIPCHK(hipStreamSynchronize(g_copy_stream));
+}
 float event_elapsed_ms(void* a, void* b) {
   HIPCHK(hipEventSynchronize((hipEvent_t)b));
   float ms = 0.f;

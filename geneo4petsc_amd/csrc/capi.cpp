@@ -680,14 +680,19 @@ PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const dou
   bk::h2d(dS, S, sizeof(double) * (size_t)n * p);
   void* e0 = bk::event_create();
   void* e1 = bk::event_create();
-  if (kind == 0) {
+  if (kind == 0 || kind == 2) {
+    // kind 2: the left operand as TWO strided views (columns [0, p/2) and [p/2, p) of S: what LOBPCG passes as A W, B W)
     double* dT = (double*)bk::alloc(sizeof(double) * (size_t)n * q);
     double* dG = (double*)bk::alloc(sizeof(double) * (size_t)nsub * p * q);
     bk::h2d(dT, TC, sizeof(double) * (size_t)n * q);
-    bk::gram(c, dS, p, p, dT, q, q, dG);
+    auto run = [&]() {
+      if (kind == 0) bk::gram(c, dS, p, p, dT, q, q, dG);
+      else bk::gram2(c, dS, p, p / 2, dS + p / 2, p, p - p / 2, dT, q, q, dG);
+    };
+    run();
     if (reps > 0) {
       bk::event_record(e0);
-      for (int i = 0; i < reps; ++i) bk::gram(c, dS, p, p, dT, q, q, dG);
+      for (int i = 0; i < reps; ++i) run();
       bk::event_record(e1);
       if (ms_avg) *ms_avg = bk::event_elapsed_ms(e0, e1) / reps;
     }

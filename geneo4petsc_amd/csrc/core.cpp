@@ -20,6 +20,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <functional>
 #include <map>
 #include <numeric>
@@ -1140,6 +1143,94 @@ int PC::eigen_dense_host() {
   return 0;
 }
 
+// Persistent host workers for the per-subdomain dense work inside the LOBPCG loop (Rayleigh-Ritz, Gram propagation):
+// creating and joining eight std::threads costs ~0.18 ms per round on the GPU box's host, two rounds per iteration.
+// run(s0, s1, f) calls f(s) for every s in [s0, s1) on the workers plus the calling thread and returns when all are done.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  void run(int s0, int s1, const std::function<void(int)>& f) {
+    if (s1 - s0 <= 1 || workers.empty()) {
+      for (int s = s0; s < s1; ++s) f(s);
+      return;
+    }
+    std::exception_ptr err;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      fn = &f;
+      next = s0;
+      end = s1;
+      pending = s1 - s0;
+      perr = &err;
+      ++generation;
+    }
+    cv.notify_all();
+    work();                                   // the caller takes its share
+    std::unique_lock<std::mutex> lk(mu);
+    done_cv.wait(lk, [&] { return pending == 0; });
+    fn = nullptr;
+    if (err) std::rethrow_exception(err);
+  }
+  ~HostPool() {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : workers) t.join();
+  }
+
+ private:
+  HostPool() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n = (int)std::min(15u, hw > 1 ? hw - 1 : 0u);
+    for (int i = 0; i < n; ++i)
+      workers.emplace_back([this]() {
+        unsigned long long seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+          }
+          work();
+        }
+      });
+  }
+  void work() {
+    for (;;) {
+      int s;
+      const std::function<void(int)>* f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!fn || next >= end) return;
+        s = next++;
+        f = fn;
+      }
+      try {
+        (*f)(s);
+      } catch (...) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (perr && !*perr) *perr = std::current_exception();
+      }
+      std::unique_lock<std::mutex> lk(mu);
+      if (--pending == 0) done_cv.notify_all();
+    }
+  }
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  const std::function<void(int)>* fn = nullptr;
+  std::exception_ptr* perr = nullptr;
+  int next = 0, end = 0, pending = 0;
+  unsigned long long generation = 0;
+  bool stop = false;
+};
+
 // LOBPCG on a pencil A v = lambda B v (lowest eigenvalues) for all local subdomains in lock step.
 // Basis S = [X | P | W] (n_L x 3m row-major).  Per iteration and subdomain:
 //   W = T (A X - B X Lambda)              T = AMG V-cycle of A, or Chebyshev(degree, Jacobi) on A   (SpMM)
@@ -1157,11 +1248,18 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   double *S = dv(blk), *AS = dv(blk), *BS = dv(blk), *T = dv(blk), *AT = dv(blk), *BT = dv(blk);
   double *cr = dv((size_t)nL * m), *cd = dv((size_t)nL * m), *cad = dv((size_t)nL * m);
   double *dGA = dv((size_t)ns * p3 * p3), *dGB = dv((size_t)ns * p3 * p3), *dC = dv((size_t)ns * p3 * 2 * m);
+  double* dGW = dv((size_t)ns * 2 * m * p3);
   double *dlam = dv((size_t)ns * m), *dnr = dv((size_t)ns * m), *dna = dv((size_t)ns * m), *dnb = dv((size_t)ns * m);
-  std::vector<double*> owned_bufs = {S, AS, BS, T, AT, BT, cr, cd, cad, dGA, dGB, dC, dlam, dnr, dna, dnb};
+  std::vector<double*> owned_bufs = {S, AS, BS, T, AT, BT, cr, cd, cad, dGA, dGB, dGW, dC, dlam, dnr, dna, dnb};
   void** graphs_to_free = nullptr;
+  bk::Chunks* groups_to_free = nullptr;
+  void** events_to_free = nullptr;
   auto cleanup = [&]() {
     for (double* p : owned_bufs) bk::dfree(p);
+    for (int i = 0; i < 2; ++i) {
+      if (groups_to_free && groups_to_free[i].start) bk::chunks_free(groups_to_free[i]);
+      if (events_to_free && events_to_free[i]) bk::event_destroy(events_to_free[i]);
+    }
     if (graphs_to_free)
       for (int i = 0; i < 2; ++i) bk::graph_destroy(graphs_to_free[i]);
   };
@@ -1170,7 +1268,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(*P.B, X, p3, Y, p3, m, P.Bs, P.Bs); info.eig_spmm++; };
 
   std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
-  std::vector<double> hGw((size_t)ns * m * p3);
+  std::vector<double> hGw((size_t)ns * 2 * m * p3);   // W rows of both Gram matrices: [(A W)^T S ; (B W)^T S] per subdomain
   bool have_prop = false;
   bool fused_update = false;  // set below, once the convergence test is known (m = 32, shift-invert test, MFMA on)
   bool have_R = false;        // the residual block of the current X is already in `cr` (written by the fused update)
@@ -1193,6 +1291,29 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   dkeep = dv((size_t)ns * m);
   owned_bufs.push_back(dkeep);
   void* it_graph[2] = {nullptr, nullptr};                       // HIP graphs of the device phase, one per buffer parity
+  bool graph_has_gram[2] = {true, true};
+  // two groups of subdomains for the pipelined host part (see `pipe` in the loop): chunk lists and Gram events
+  // (opt-in, GENEO_LOBPCG_PIPELINE=1: measured on the 126^3 bench it shortens the GPU's wait for the host by 60 ms per
+  // eigensolve and gives as much back in host-side synchronisation -- see DESIGN.md section 7)
+  static const bool want_pipeline = getenv("GENEO_LOBPCG_PIPELINE") != nullptr;
+  const bool pipeline_ok = ns >= 2 && want_pipeline;
+  int grp[3] = {0, ns, ns};
+  bk::Chunks chg[2];
+  void* gram_ev[2] = {nullptr, nullptr};
+  if (pipeline_ok) {
+    std::vector<int> so(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) so[s + 1] = so[s] + (int)subs[s].l2g.size();
+    int cut = 1;                                                 // the split that balances the rows of the two groups
+    for (int s = 1; s < ns; ++s)
+      if (std::abs(2 * (int64_t)so[s] - so[ns]) < std::abs(2 * (int64_t)so[cut] - so[ns])) cut = s;
+    grp[1] = cut;
+    chg[0] = bk::chunks_upload(cut, so.data());
+    chg[1] = bk::chunks_upload(ns - cut, so.data() + cut);
+    gram_ev[0] = bk::event_create();
+    gram_ev[1] = bk::event_create();
+  }
+  groups_to_free = chg;
+  events_to_free = gram_ev;
   bool it_graph_failed = false;
   static const bool no_graph = getenv("GENEO_LOBPCG_NO_GRAPH") != nullptr;
   graphs_to_free = it_graph;
@@ -1218,18 +1339,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   // they are needed only when its Gram rows come back, so they cost no GPU idle time.
   std::vector<double> hSA((size_t)ns * p3 * p3), hSB((size_t)ns * p3 * p3);   // symmetrised blocks the last RR used
   bool prop_pending = false;
-  auto on_host_threads = [&](const std::function<void(int)>& f) {
-    const int nth = std::max(1, std::min(ns, (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
-    if (nth == 1) {
-      for (int s = 0; s < ns; ++s) f(s);
-      return;
-    }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t)
-      th.emplace_back([&, t]() {
-        for (int s = t; s < ns; s += nth) f(s);
-      });
-    for (auto& x : th) x.join();
+  auto on_host_threads = [&](const std::function<void(int)>& f, int s0 = 0, int s1 = -1) {
+    HostPool::get().run(s0, s1 < 0 ? ns : s1, f);
   };
   auto run_propagate = [&]() {
     if (!prop_pending) return;
@@ -1267,9 +1378,14 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     });
     t_prop_host += secs(tg, clk::now());
   };
-  auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p) -> int {
+  // Subdomains [s0, s1) (all of them by default) with the chunk list `cg` of exactly those rows; `last`: the basis
+  // buffers swap roles once the last group has been updated.
+  auto rayleigh_ritz = [&](int p, int nfix, int qout, bool with_p, int s0 = 0, int s1 = -1, const bk::Chunks* cg = nullptr,
+                           bool last = true) -> int {
+    if (s1 < 0) s1 = ns;
+    if (!cg) cg = &ch;
     auto tg1 = clk::now();
-    std::fill(hC.begin(), hC.end(), 0.0);
+    std::fill(hC.begin() + (size_t)s0 * p * qout, hC.begin() + (size_t)s1 * p * qout, 0.0);
     const bool want_prop = (p == p3) && conv_sinvert_now;
     auto rr_one = [&](int s) {
       std::vector<double> ga(hGA.begin() + (size_t)s * p * p, hGA.begin() + (size_t)(s + 1) * p * p);
@@ -1303,27 +1419,29 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         }
       }
     };
-    on_host_threads(rr_one);   // the per-subdomain projected problems are independent: one host thread each (bounded)
-    if (want_prop) {
+    on_host_threads(rr_one, s0, s1);   // the per-subdomain projected problems are independent: one host thread each (bounded)
+    if (want_prop && last) {
       prop_pending = true;   // hGA / hGB will hold the [X P] blocks of the new basis once run_propagate has run
       have_prop = true;
     }
     t_rr_host += secs(tg1, clk::now());
-    bk::h2d(dC, hC.data(), sizeof(double) * (size_t)ns * p * qout);
-    have_R = false;
+    const size_t co = (size_t)s0 * p * qout, mo = (size_t)s0 * m;    // the group's offsets in the per-subdomain arrays
+    bk::h2d(dC + co, hC.data() + co, sizeof(double) * (size_t)(s1 - s0) * p * qout);
     if (fused_update && p == p3 && with_p) {
       // one launch: [X' P'] for S, A S, B S (the [P W] product once per operand) and the next residual block
-      for (size_t e = 0; e < keep.size(); ++e) keep[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-      bk::h2d(dkeep, keep.data(), sizeof(double) * keep.size());
-      bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
-      bk::lobpcg_update32(ch, S, AS, BS, dC, dkeep, dlam, dmask, T, AT, BT, cr);
-      have_R = true;
+      for (size_t e = mo; e < (size_t)s1 * m; ++e) keep[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+      bk::h2d(dkeep + mo, keep.data() + mo, sizeof(double) * (size_t)(s1 - s0) * m);
+      bk::h2d(dlam + mo, lam.data() + mo, sizeof(double) * (size_t)(s1 - s0) * m);
+      bk::lobpcg_update32(*cg, S, AS, BS, dC + co, dkeep + mo, dlam + mo, dmask + mo, T, AT, BT, cr);
+      if (last) have_R = true;
     } else {
+      if (s0 != 0 || s1 != ns) throw std::runtime_error("lobpcg: grouped update without the fused kernel");
+      have_R = false;
       bk::block_mul(ch, S, p3, p, dC, qout, T, p3, false);
       bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
       bk::block_mul(ch, BS, p3, p, dC, qout, BT, p3, false);
     }
-    std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT);
+    if (last) { std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT); }
     return 0;
   };
   gram_blocks(m);
@@ -1362,9 +1480,10 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   const double tol_lock = lock_at_tol ? tol : std::max(tol * tol, std::min(tol, 1e-10));
   std::vector<char> conv((size_t)ns * m, 0);
   // locks + frozen subdomains from res[][]; returns true when every subdomain is done
-  auto update_locks = [&]() {
+  auto update_locks = [&](int s0 = 0, int s1 = -1) {
     bool done = true;
-    for (int s = 0; s < ns; ++s) {
+    if (s1 < 0) s1 = ns;
+    for (int s = s0; s < s1; ++s) {
       if (frozen[s]) continue;
       bool sub_done = true;
       for (int j = 0; j < m; ++j) {
@@ -1431,8 +1550,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       applyA(S, AS);
       applyB(S, BS);
     }
-    // residual into the W slot, convergence test
-    bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
+    // residual into the W slot, convergence test (the fused update has already uploaded the Ritz values it used)
+    if (!have_R || refreshed) bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
     double* W = S + 2 * m;
     // The device part of one iteration -- residual, preconditioner, A W, B W, the two Gram blocks: ~45 launches, many of
     // them on the small coarse levels of the V-cycle where the host cannot issue as fast as the GPU retires.  With the
@@ -1459,16 +1578,21 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       }
     };
     const bool reduced = have_prop && !full_gram && !(refresh > 0 && it % refresh == 0);
-    auto device_phase = [&]() {
+    // Two-stage pipeline of the host part (pipe): the subdomains are split into two groups; each group has its own Gram
+    // launches, Rayleigh-Ritz and update launch.  While the host solves the projected problems of group 0 the GPU
+    // computes the Gram rows of group 1, and while it solves those of group 1 the GPU updates the basis of group 0:
+    // of the ~1.3 ms per iteration the GPU used to wait for the host, ~0.3 ms are left.
+    const bool pipe = pipeline_ok && reduced && fused_update && conv_sinvert;
+    auto device_phase = [&](bool with_gram) {
       // residual block (columns locked in EARLIER iterations come out zero): already written by the fused update,
       // unless A X / B X have just been refreshed
       if (!have_R || refreshed) bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);
       precondition();
       applyA(W, AS + 2 * m);
       applyB(W, BS + 2 * m);
-      if (reduced) {       // (A W)^T [X P W] and (B W)^T [X P W]: the W rows of the two Gram matrices
-        bk::gram(ch, AS + 2 * m, p3, m, S, p3, p3, dGA);
-        bk::gram(ch, BS + 2 * m, p3, m, S, p3, p3, dGB);
+      if (!with_gram) return;
+      if (reduced) {       // (A W)^T [X P W] and (B W)^T [X P W]: the W rows of the two Gram matrices, one pass over S
+        bk::gram2(ch, AS + 2 * m, p3, m, BS + 2 * m, p3, m, S, p3, p3, dGW);
       } else {
         bk::gram(ch, S, p3, p3, AS, p3, p3, dGA);
         bk::gram(ch, S, p3, p3, BS, p3, p3, dGB);
@@ -1491,46 +1615,68 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       applyA(W, AS + 2 * m);
       applyB(W, BS + 2 * m);
       gram_blocks(p3);
-    } else {
-      // it 0 runs direct (first calls size scratch buffers); while bench.py's in-situ kernel timer is on every 8th
-      // iteration runs direct so that its launches can be bracketed by events (graph nodes cannot)
-      const int par = it & 1;
-      const bool direct = no_graph || !reduced || (fused_update && !have_R) || (bk::spmv_profiling() && it % 8 == 1);
-      if (!direct && !it_graph[par] && !it_graph_failed) {
-        const int spmm_before = info.eig_spmm;
-        if (bk::graph_capture_begin()) {
-          try {
-            device_phase();
-          } catch (...) {
-            bk::graph_capture_end();
-            throw;
-          }
-          it_graph[par] = bk::graph_capture_end();
+      bool changed = false;
+      for (size_t e = 0; e < locked.size(); ++e) {
+        const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+        if (mk != mask[e]) changed = true;
+        mask[e] = mk;
+      }
+      if (changed) bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
+      lam_prev = lam;
+      rayleigh_ritz(p3, m, 2 * m, true);
+      continue;
+    }
+    // it 0 runs direct (first calls size scratch buffers); while bench.py's in-situ kernel timer is on every 8th
+    // iteration runs direct so that its launches can be bracketed by events (graph nodes cannot)
+    const int par = it & 1;
+    const bool direct = no_graph || !reduced || (fused_update && !have_R) || (bk::spmv_profiling() && it % 8 == 1);
+    if (!direct && !it_graph[par] && !it_graph_failed) {
+      const int spmm_before = info.eig_spmm;
+      if (bk::graph_capture_begin()) {
+        try {
+          device_phase(!pipe);
+        } catch (...) {
+          bk::graph_capture_end();
+          throw;
         }
-        info.eig_spmm = spmm_before;   // recorded, not run
-        if (!it_graph[par]) it_graph_failed = true;
+        it_graph[par] = bk::graph_capture_end();
+        graph_has_gram[par] = !pipe;
       }
-      if (!direct && it_graph[par]) {
-        bk::graph_launch(it_graph[par]);
-        info.eig_spmm += P.amg ? 5 : 2 + opt.cheb_degree - 1;   // what device_phase counts when it runs direct
-      } else {
-        device_phase();
+      info.eig_spmm = spmm_before;   // recorded, not run
+      if (!it_graph[par]) it_graph_failed = true;
+    }
+    if (!direct && it_graph[par] && graph_has_gram[par] == !pipe) {
+      bk::graph_launch(it_graph[par]);
+      info.eig_spmm += P.amg ? 5 : 2 + opt.cheb_degree - 1;   // what device_phase counts when it runs direct
+    } else {
+      device_phase(!pipe);
+    }
+    const int ngr = pipe ? 2 : 1;
+    if (pipe)
+      for (int g = 0; g < 2; ++g) {      // the Gram rows of each group, an event behind each pair of launches
+        bk::gram2(chg[g], AS + 2 * m, p3, m, BS + 2 * m, p3, m, S, p3, p3, dGW + (size_t)grp[g] * 2 * m * p3);
+        bk::event_record(gram_ev[g]);
       }
-      if (reduced) run_propagate();          // host work hidden behind the launches above
-      else prop_pending = false;             // the explicit 96 x 96 blocks are on their way
+    if (reduced) run_propagate();          // host work hidden behind the launches above
+    else prop_pending = false;             // the explicit 96 x 96 blocks are on their way
+    bool all = true, stop = false;
+    for (int g = 0; g < ngr; ++g) {
+      const int s0 = pipe ? grp[g] : 0, s1 = pipe ? grp[g + 1] : ns;
       auto tg0 = clk::now();
       if (reduced) {
+        const size_t go = (size_t)s0 * 2 * m * p3, gn = (size_t)(s1 - s0) * 2 * m * p3;
+        if (pipe) bk::d2h_after(hGw.data() + go, dGW + go, sizeof(double) * gn, gram_ev[g]);
+        else bk::d2h(hGw.data() + go, dGW + go, sizeof(double) * gn);
         for (int which = 0; which < 2; ++which) {
-          bk::d2h(hGw.data(), which ? dGB : dGA, sizeof(double) * (size_t)ns * m * p3);
           std::vector<double>& G = which ? hGB : hGA;
-          for (int sd = 0; sd < ns; ++sd) {
-            double* g = G.data() + (size_t)sd * p3 * p3;
-            const double* gw = hGw.data() + (size_t)sd * m * p3;
+          for (int sd = s0; sd < s1; ++sd) {
+            double* gm = G.data() + (size_t)sd * p3 * p3;
+            const double* gw = hGw.data() + ((size_t)sd * 2 + which) * m * p3;
             for (int a = 0; a < m; ++a)
               for (int b = 0; b < p3; ++b) {
                 const double v = gw[(size_t)a * p3 + b];
-                g[(size_t)(2 * m + a) * p3 + b] = v;
-                if (b < 2 * m) g[(size_t)b * p3 + 2 * m + a] = v;
+                gm[(size_t)(2 * m + a) * p3 + b] = v;
+                if (b < 2 * m) gm[(size_t)b * p3 + 2 * m + a] = v;
               }
           }
         }
@@ -1539,30 +1685,35 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         bk::d2h(hGB.data(), dGB, sizeof(double) * (size_t)ns * p3 * p3);
       }
       t_dev_wait += secs(tg0, clk::now());
-    }
-    if (conv_sinvert) {
       // || T r_j ||_B / || x_j ||_B off the diagonal of S^T B S (columns masked earlier have W_j = 0: they stay locked)
-      for (int s = 0; s < ns; ++s)
+      for (int s = s0; s < s1; ++s)
         for (int j = 0; j < m; ++j) {
           const double* gb = hGB.data() + (size_t)s * p3 * p3;
           const double ww = gb[(size_t)(2 * m + j) * p3 + 2 * m + j], xx = gb[(size_t)j * p3 + j];
           res[s][j] = (xx > 0.0 && ww > 0.0) ? std::sqrt(ww / xx) : 0.0;
         }
-      all_done = update_locks();
-      debug_line();
-      if (all_done || it == opt.eps_max_it) break;
+      all = update_locks(s0, s1) && all;
+      if (g == ngr - 1) {
+        // (with two groups the first one has been updated already when the last one turns out to be the last to
+        // converge: its new blocks went to the T buffers, which are simply not swapped in; a group that still had
+        // an unconverged subdomain rules `all` out, so no Ritz value of a finished run is ever overwritten)
+        all_done = all;
+        debug_line();
+        if (all_done || it == opt.eps_max_it) { stop = true; break; }
+      }
+      // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
+      // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
+      bool changed = false;
+      for (size_t e = (size_t)s0 * m; e < (size_t)s1 * m; ++e) {
+        const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
+        if (mk != mask[e]) changed = true;
+        mask[e] = mk;
+      }
+      if (changed) bk::h2d(dmask + (size_t)s0 * m, mask.data() + (size_t)s0 * m, sizeof(double) * (size_t)(s1 - s0) * m);
+      std::copy(lam.begin() + (size_t)s0 * m, lam.begin() + (size_t)s1 * m, lam_prev.begin() + (size_t)s0 * m);
+      rayleigh_ritz(p3, m, 2 * m, true, s0, s1, pipe ? &chg[g] : &ch, g == ngr - 1);
     }
-    // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
-    // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
-    bool changed = false;
-    for (size_t e = 0; e < locked.size(); ++e) {
-      const double mk = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-      if (mk != mask[e]) changed = true;
-      mask[e] = mk;
-    }
-    if (changed) bk::h2d(dmask, mask.data(), sizeof(double) * mask.size());
-    lam_prev = lam;
-    rayleigh_ritz(p3, m, 2 * m, true);
+    if (stop) break;
   }
   info.eig_iterations += it;
   if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);

@@ -406,14 +406,15 @@ class Spmv:
 
 
 def block_kernel(kind, suboff, S, TC, lib=None, reps=0):
-    """kind 0: per-subdomain Gram S^T T ; kind 1: per-subdomain S C.  Returns (result, ms_avg)."""
+    """kind 0: per-subdomain Gram S^T T (kind 2: the same through the two-left-block entry) ; kind 1: per-subdomain
+    S C.  Returns (result, ms_avg)."""
     lib = lib if lib is not None else L.load()
     suboff = np.ascontiguousarray(suboff, dtype=np.int32)
     nsub = len(suboff) - 1
     S = np.ascontiguousarray(S, dtype=np.float64)
     TC = np.ascontiguousarray(TC, dtype=np.float64)
     n, p = S.shape
-    if kind == 0:
+    if kind in (0, 2):
         q = TC.shape[1]
         out = np.zeros((nsub, p, q))
     else:

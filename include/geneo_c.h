@@ -269,6 +269,7 @@ long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, i
                                  double* val_out, long long cap);
 /* per-subdomain tall-skinny kernels on host data (suboff: nsub+1 row offsets):
  *   kind 0: G[s] = S_s^T T_s (p x q)     kind 1: Y_s = S_s C_s (C: nsub x p x q)
+ *   kind 2: kind 0 through the two-left-block entry (columns [0, p/2) and [p/2, p) of S passed as separate views)
  * GeneoSetMFMA(0) selects the plain-FMA twin.  reps > 0 also times it (HIP events). */
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* T_or_C,
                                 int q, double* out, int reps, double* ms_avg);

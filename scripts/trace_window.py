@@ -15,6 +15,14 @@ if not hits:
     sys.exit("no kernel matching %r" % anchor)
 k = int(sys.argv[3]) if len(sys.argv) > 3 and int(sys.argv[3]) >= 0 else len(hits) // 2
 cnt = int(sys.argv[4]) if len(sys.argv) > 4 else 120
+if cnt == 0:     # intervals between successive anchor launches instead of a window
+    prev = None
+    for j, i in enumerate(hits):
+        if prev is not None:
+            print("%4d  +%9.1f us" % (j, (rows[i][0] - prev) / 1e3))
+        prev = rows[i][0]
+    print("total %.1f ms over %d anchors" % ((rows[hits[-1]][0] - rows[hits[0]][0]) / 1e6, len(hits)))
+    sys.exit(0)
 i0 = hits[min(k, len(hits) - 1)]
 t0 = rows[i0][0]
 busy = idle = 0

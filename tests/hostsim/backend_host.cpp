@@ -232,7 +232,7 @@ void dot(const double* x, const double* y, int n, double* out) {
 Chunks chunks_upload(int nsub, const int* off) {
   Chunks c;
   c.nsub = nsub;
-  c.n = off[nsub];
+  c.n = off[nsub] - off[0];
   std::vector<int> st, ln, sb, sp;
   sp.push_back(0);
   for (int s = 0; s < nsub; ++s) {
@@ -348,6 +348,20 @@ void gram(const Chunks& c, const double* S, int lds, int p, const double* T, int
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
       for (int a = 0; a < p; ++a) {
         const double sv = S[(int64_t)i * lds + a];
+        if (sv == 0.0) continue;
+        for (int b = 0; b < q; ++b) g[a * q + b] += sv * T[(int64_t)i * ldt + b];
+      }
+  }
+}
+void gram2(const Chunks& c, const double* S1, int lds1, int p1, const double* S2, int lds2, int p2, const double* T, int ldt,
+           int q, double* G) {
+  const int p = p1 + p2;
+  for (int s = 0; s < c.nsub; ++s) {
+    double* g = G + (int64_t)s * p * q;
+    for (int e = 0; e < p * q; ++e) g[e] = 0;
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+      for (int a = 0; a < p; ++a) {
+        const double sv = a < p1 ? S1[(int64_t)i * lds1 + a] : S2[(int64_t)i * lds2 + a - p1];
         if (sv == 0.0) continue;
         for (int b = 0; b < q; ++b) g[a * q + b] += sv * T[(int64_t)i * ldt + b];
       }
@@ -511,6 +525,7 @@ const char* spmv_kernel_name() { return "hostsim"; }
 int selftest_mfma_f64() { return 0; }
 void* event_create() { return nullptr; }
 void event_record(void*) {}
+void d2h_after(void* h, const void* d, size_t b, void*) { if (b) memcpy(h, d, b); }
 float event_elapsed_ms(void*, void*) { return 0.f; }
 void event_destroy(void*) {}
 bool lobpcg_update32_available() { return true; }

@@ -225,6 +225,24 @@ def test_gram(lib, p, q, mfma):
         np.testing.assert_allclose(G[s], S[a:b].T @ T[a:b], rtol=1e-12, atol=1e-11)
 
 
+@pytest.mark.parametrize("p,q", [(64, 96), (32, 96), (128, 64), (24, 12)])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_gram_two_left_blocks(lib, p, q, mfma):
+    """gram2: [(A W)^T S ; (B W)^T S] in one pass over S (the reduced Gram rows of LOBPCG, p = 64, q = 96)."""
+    from geneo4petsc_amd.pc import block_kernel
+    rng = np.random.default_rng(41)
+    suboff = np.array([0, 700, 1500, 1501, 4000], dtype=np.int32)
+    S, T = rng.random((4000, p)) - 0.5, rng.random((4000, q)) - 0.5
+    lib.GeneoSetMFMA(mfma)
+    try:
+        g, _ = block_kernel(2, suboff, S, T, lib)
+    finally:
+        lib.GeneoSetMFMA(1)
+    for s in range(4):
+        r = slice(suboff[s], suboff[s + 1])
+        np.testing.assert_allclose(g[s], S[r].T @ T[r], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("p,q", [(16, 16), (32, 32), (48, 32), (96, 64), (64, 64), (192, 128), (96, 32), (20, 12)])
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_block_mul(lib, p, q, mfma):
