@@ -23,6 +23,7 @@ void sync();                              // wait for the stream
 
 void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
 void  dfree(void* p);
+void  alloc_cache_release();   // hipFree every block the caching allocator holds (backend_hip.hip: alloc)
 void  alloc_stats(double* alloc_s, double* free_s, long long* n);   // time spent in hipMalloc / hipFree since the last call
 void  h2d(void* d, const void* h, size_t bytes);
 void  d2h(void* h, const void* d, size_t bytes);   // synchronous w.r.t. the stream

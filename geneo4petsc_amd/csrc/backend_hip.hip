@@ -20,6 +20,9 @@
 #include <chrono>
 #include <cstring>
 #include <thread>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "backend.h"
@@ -54,22 +57,89 @@ void sync() { HIPCHK(hipStreamSynchronize(g_stream)); }
 
 static double g_alloc_s = 0.0, g_free_s = 0.0;
 static long long g_alloc_n = 0;
+// Caching allocator.  hipMalloc of a multi-GB block costs ~18 ms per GB on this system (184^3 per GPU: 0.9 s of a 2.5 s
+// set-up went into hipMalloc, most of it for blocks an earlier phase had just given back) and hipFree synchronises the
+// device.  Freed blocks are kept (by size) and handed out again: to the next phase of the same set-up (the LOBPCG basis
+// buffers become the blocks of the coarse-operator assembly) and to the next set-up of the process.  Every use of a
+// block is ordered on the library stream, so a block may be reused without waiting for its last kernel.  The cache is
+// released when a preconditioner is destroyed (alloc_cache_release), when hipMalloc fails, and never grows beyond
+// GENEO_ALLOC_CACHE_GB (default 96); GENEO_ALLOC_CACHE=0 turns it off.
+static std::mutex g_alloc_mu;
+static std::unordered_map<void*, size_t> g_live;
+static std::multimap<size_t, void*> g_cache;
+static size_t g_cache_bytes = 0;
+static bool alloc_cache_on() {
+  static const bool on = !(getenv("GENEO_ALLOC_CACHE") && !strcmp(getenv("GENEO_ALLOC_CACHE"), "0"));
+  return on;
+}
+static size_t alloc_cache_cap() {
+  static const size_t cap = (size_t)(getenv("GENEO_ALLOC_CACHE_GB") ? atof(getenv("GENEO_ALLOC_CACHE_GB")) : 96.0) << 30;
+  return cap;
+}
+static inline size_t alloc_round(size_t bytes) {
+  const size_t g = bytes < ((size_t)1 << 20) ? 512 : ((size_t)2 << 20);
+  return (bytes + g - 1) / g * g;
+}
+void alloc_cache_release() {
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  if (g_cache.empty()) return;
+  auto t0 = std::chrono::high_resolution_clock::now();
+  (void)hipStreamSynchronize(g_stream);
+  for (auto& kv : g_cache) (void)hipFree(kv.second);
+  g_cache.clear();
+  g_cache_bytes = 0;
+  g_free_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+}
 void* alloc(size_t bytes) {
   lazy_init();
   void* p = nullptr;
   if (bytes == 0) bytes = 8;
-  auto t0 = std::chrono::high_resolution_clock::now();
-  HIPCHK(hipMalloc(&p, bytes));
-  const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-  g_alloc_s += dt;
-  ++g_alloc_n;
-  static const bool trace = getenv("GENEO_ALLOC_TRACE") != nullptr;
-  if (trace && dt > 2e-4) fprintf(stderr, "[alloc] %.1f MB in %.3f ms\n", bytes / 1e6, dt * 1e3);
+  const size_t sz = alloc_cache_on() ? alloc_round(bytes) : bytes;
+  if (alloc_cache_on()) {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_cache.lower_bound(sz);
+    if (it != g_cache.end() && it->first <= sz + sz / 8 + 4096) {
+      p = it->second;
+      g_live[p] = it->first;
+      g_cache_bytes -= it->first;
+      g_cache.erase(it);
+    }
+  }
+  if (!p) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess && alloc_cache_on()) {     // out of memory with blocks parked in the cache: give them back, once
+      (void)hipGetLastError();
+      alloc_cache_release();
+      e = hipMalloc(&p, sz);
+    }
+    HIPCHK(e);
+    const double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    static const bool trace = getenv("GENEO_ALLOC_TRACE") != nullptr;
+    if (trace && dt > 2e-4) fprintf(stderr, "[alloc] %.1f MB in %.3f ms\n", sz / 1e6, dt * 1e3);
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_alloc_s += dt;
+    ++g_alloc_n;
+    if (alloc_cache_on()) g_live[p] = sz;
+  }
   HIPCHK(hipMemsetAsync(p, 0, bytes, g_stream));
   return p;
 }
 void dfree(void* p) {
   if (!p) return;
+  if (alloc_cache_on()) {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) {
+      const size_t sz = it->second;
+      g_live.erase(it);
+      if (g_cache_bytes + sz <= alloc_cache_cap()) {
+        g_cache.emplace(sz, p);
+        g_cache_bytes += sz;
+        return;
+      }
+    }
+  }
   auto t0 = std::chrono::high_resolution_clock::now();
   (void)hipFree(p);
   g_free_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();

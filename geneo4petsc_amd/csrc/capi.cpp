@@ -70,6 +70,7 @@ PetscErrorCode PCDestroy_GenEO(PC* pc) {
   delete (*pc)->ctx;
   delete *pc;
   *pc = nullptr;
+  bk::alloc_cache_release();      // blocks parked by the caching allocator go back to the device
   GUARD_END((PC) nullptr)
   return 0;
 }

@@ -525,6 +525,7 @@ const char* spmv_kernel_name() { return "hostsim"; }
 int selftest_mfma_f64() { return 0; }
 void* event_create() { return nullptr; }
 void event_record(void*) {}
+void alloc_cache_release() {}
 void d2h_after(void* h, const void* d, size_t b, void*) { if (b) memcpy(h, d, b); }
 float event_elapsed_ms(void*, void*) { return 0.f; }
 void event_destroy(void*) {}
