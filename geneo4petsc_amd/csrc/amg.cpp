@@ -367,6 +367,7 @@ AmgDevice::~AmgDevice() { free_all(); }
 void AmgDevice::free_all() {
   for (auto& L : lv) {
     bk::csr_free(L.Acs);
+    bk::csr_free(L.M);
     if (L.own_A) bk::csr_free(L.A);
     else bk::csr_free_lp(L.A);    // the companion of a borrowed matrix is ours
     bk::csr_free(L.P);
@@ -407,7 +408,10 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
     bk::h2d(L.dinv, H.dinv.data(), sizeof(double) * L.n);
     alloc_level_buffers(L, l > 0);
     L.fused = bk::csr_fusable(L.A) && (l + 1 == (int)levels.size() || bk::csr_fusable(L.P)) && !getenv("GENEO_AMG_UNFUSED");
-    if (l + 1 < levels.size()) make_column_scaled(L);
+    if (l + 1 < levels.size()) {
+      make_column_scaled(L);
+      make_post_matrix(L, nullptr, levels[l + 1].n);
+    }
     if (l == 0) nnz0 = (double)H.nnz;
     nnzt += (double)H.nnz;
     lv.push_back(L);
@@ -435,7 +439,42 @@ void AmgDevice::make_single() {
     if (L.Acs.n && bk::csr_make_lp(L.Acs, &L.A)) ++nlp;
     if (L.P.n && bk::csr_make_lp(L.P)) ++nlp;
     if (L.R.n && bk::csr_make_lp(L.R)) ++nlp;
+    if (L.M.n && bk::csr_make_lp(L.M)) ++nlp;
   }
+}
+
+double AmgDevice::jacobi_weight(const Lvl& L) const {
+  const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
+  return 1.0 / (0.5 * (lmax + lmin));
+}
+
+// The post-smoothing half of the damped-Jacobi V-cycle in one product.  With x1 = w D^-1 b and r1 = b - A x1 from the
+// zero-guess sweep (EPI_PRE) and e the coarse correction:
+//     t = x1 + P e ,  x = t + w D^-1 (b - A t)   =   x1 + w D^-1 r1 + (P - w D^-1 A P) e
+// so the prolongation, the correction and the sweep cost ONE pass over M = P - w D^-1 A P (about the entries of A, and
+// it gathers the small coarse vector, not a fine one) instead of a pass over P and a pass over A with a fine gather:
+// three fine-vector passes (x1, r1 in, x out) instead of five.  A P is a by-product of the Galerkin product (device
+// set-up) or one more device sparse product (host set-up).  `ap` (consumed) may be null.
+void AmgDevice::make_post_matrix(Lvl& L, bk::Csr* ap, int nc) {
+  const bool want = prm.smooth_degree <= 1 && L.fused && !getenv("GENEO_AMG_NO_POST_MATRIX");
+  bk::Csr AP;
+  bool ok = true;
+  if (ap) AP = *ap;
+  else if (want) AP = bk::spgemm(L.A, L.P, nc, &ok);
+  if (!want || !ok || AP.n == 0) {
+    if (AP.n) bk::csr_free(AP);
+    return;
+  }
+  if (!bk::post_matrix(AP, L.P, L.dinv, jacobi_weight(L))) {
+    bk::csr_free(AP);
+    return;
+  }
+  bk::csr_finish(AP);
+  if (!bk::csr_fusable(AP)) {     // long rows: stay with the two-launch form
+    bk::csr_free(AP);
+    return;
+  }
+  L.M = AP;
 }
 
 void AmgDevice::make_column_scaled(Lvl& L) {
@@ -545,8 +584,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     bk::Csr AP = bk::spgemm(Adev, P, nc, &ok);
     if (!ok) { bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
     bk::Csr Ac = bk::spgemm(R, AP, nc, &ok);
-    bk::csr_free(AP);
-    if (!ok) { bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
+    if (!ok) { bk::csr_free(AP); bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
     bk::csr_finish(P);
     bk::csr_finish(R);
     bk::csr_finish(Ac);
@@ -556,6 +594,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     alloc_level_buffers(L, l > 0);
     L.fused = bk::csr_fusable(L.A) && bk::csr_fusable(L.P) && !getenv("GENEO_AMG_UNFUSED");
     make_column_scaled(L);
+    make_post_matrix(L, &AP, nc);       // consumes A P
     lv.push_back(L);
     // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse
     HostCsr next;
@@ -622,8 +661,7 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
   Lvl& C0 = lv[l + 1];
   if (prm.smooth_degree <= 1 && L.fused) {
     // damped-Jacobi V-cycle in 4 launches per level: the vector passes ride on the SpMV / SpMM epilogues
-    const double lmax = 1.1 * L.rho, lmin = lmax / std::max(1.5, prm.smooth_ratio);
-    const double w = 1.0 / (0.5 * (lmax + lmin));
+    const double w = jacobi_weight(L);
     const bk::Csr& Apre = L.Acs.n ? L.Acs : L.A;
     const bool vec = (m == 1 && ldb <= 1 && ldx <= 1);     // contiguous single vectors: the companions apply
     if (vec && bk::csr_has_lp(Apre)) bk::spmv_fused_lp(Apre, bk::EPI_PRE, nullptr, L.r, B, X, L.dinv, w);
@@ -631,6 +669,11 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
     if (vec && bk::csr_has_lp(L.R)) bk::spmv_lp(L.R, L.r, C0.b);
     else applyA(L.R, L.r, m, C0.b, m, m);                                                   // restrict
     cycle(l + 1, C0.b, m, C0.x, m, m);
+    if (L.M.n) {      // x = x1 + w D^-1 r1 + (P - w D^-1 A P) e, in place on X
+      if (vec && bk::csr_has_lp(L.M)) bk::spmv_fused_lp(L.M, bk::EPI_POST, C0.x, X, L.r, X, L.dinv, w);
+      else bk::spmm_fused(L.M, bk::EPI_POST, C0.x, m, X, ldx, m, L.r, m, X, ldx, L.dinv, w);
+      return;
+    }
     if (vec && bk::csr_has_lp(L.P)) bk::spmv_fused_lp(L.P, bk::EPI_ADD, C0.x, L.d, nullptr, X, nullptr, 0.0);
     else bk::spmm_fused(L.P, bk::EPI_ADD, C0.x, m, L.d, m, m, nullptr, 0, X, ldx, nullptr, 0.0);  // t = x + P e
     if (vec && bk::csr_has_lp(L.A)) bk::spmv_fused_lp(L.A, bk::EPI_JAC, L.d, X, B, nullptr, L.dinv, w);

@@ -61,6 +61,8 @@ class AmgDevice {
   struct Lvl {
     bk::Csr A, P, R;
     bk::Csr Acs;              // A diag(dinv), values only: the zero-guess sweep (EPI_PRE) then gathers b alone
+    bk::Csr M;                // P - w D^-1 A P: prolongation, correction and the post-smoothing sweep as ONE product with
+                              // the coarse correction (EPI_POST); empty: the two-launch form (P, then the Jacobi sweep on A)
     double* dinv = nullptr;
     double *b = nullptr, *x = nullptr, *r = nullptr, *d = nullptr, *ad = nullptr;  // n x max_m work blocks
     int n = 0;
@@ -79,6 +81,8 @@ class AmgDevice {
   void make_single();
   void alloc_level_buffers(Lvl& L, bool coarse);
   void make_column_scaled(Lvl& L);
+  void make_post_matrix(Lvl& L, bk::Csr* ap, int nc);
+  double jacobi_weight(const Lvl& L) const;
   void applyA(const bk::Csr& a, const double* X, int ldx, double* Y, int ldy, int m);
   void smooth(Lvl& L, const double* B, int ldb, double* X, int ldx, int m, bool zero_guess);
   void cycle(int l, const double* B, int ldb, double* X, int ldx, int m);

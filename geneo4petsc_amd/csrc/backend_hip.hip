@@ -798,6 +798,35 @@ void smooth_prolongator(Csr& ap0, const int* agg_dev, const double* dinv_dev, do
                      dinv_dev, w);
 }
 
+// M = P - w D^-1 (A P) over the pattern of A P (one thread per row; the rows of P are short: linear search)
+__global__ void k_post_matrix(int n, const int* __restrict__ arp, const int* __restrict__ acol, double* __restrict__ aval,
+                              const int* __restrict__ prp, const int* __restrict__ pcol, const double* __restrict__ pval,
+                              const double* __restrict__ dinv, double w, int* __restrict__ miss) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int p0 = prp[i], p1 = prp[i + 1];
+    const double f = w * dinv[i];
+    int found = 0;
+    for (int k = arp[i]; k < arp[i + 1]; ++k) {
+      const int c = acol[k];
+      double v = -f * aval[k];
+      for (int q = p0; q < p1; ++q)
+        if (pcol[q] == c) { v += pval[q]; ++found; break; }
+      aval[k] = v;
+    }
+    if (found != p1 - p0) atomicExch(miss, 1);
+  }
+}
+bool post_matrix(Csr& ap, const Csr& p, const double* dinv, double w) {
+  if (ap.n == 0) return true;
+  int* dmiss = (int*)alloc(sizeof(int));
+  hipLaunchKernelGGL(k_post_matrix, dim3(gridv(ap.n)), dim3(256), 0, g_stream, ap.n, ap.rowptr, ap.col, ap.val, p.rowptr,
+                     p.col, p.val, dinv, w, dmiss);
+  int miss = 0;
+  d2h(&miss, dmiss, sizeof(int));
+  dfree(dmiss);
+  return miss == 0;
+}
+
 void csr_free_lp(Csr& a) {
   dfree(a.lp_val);
   if (!a.alias) { dfree(a.lp_col); dfree(a.lp_base); }
@@ -984,6 +1013,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
     y[r] = z[r] + sum;
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else if (EPI == EPI_POST) {
+    y[r] = z[r] + w * dinv[r] * b[r] + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
     z[r] = w * dinv[r] * bb;
@@ -1042,16 +1073,29 @@ __global__ __launch_bounds__(256) void k_spmv_sell_wide(const int64_t* __restric
     y[r] = z[r] + sum;
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else if (EPI == EPI_POST) {
+    y[r] = z[r] + w * dinv[r] * b[r] + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
     z[r] = w * dinv[r] * bb;
     y[r] = bb - w * sum;
   }
 }
-static int g_sell_wide = -1;     // average slice width from which a workgroup (not a wave) owns a slice; 0 = never
+// Average slice width from which a workgroup (not a wave) owns a slice; 0 = never.  Single vectors: 16 (measured on the
+// 126^3 hierarchy: the 12-wide post-smoothing matrix P - w D^-1 A P runs 20 % faster wave-per-slice).  Blocks: 9 -- as
+// soon as a slice needs a second 8-entry chunk the wave-per-slice SpMM re-stages it for every row group (that matrix
+// on 32 columns: 1.54 ms against 0.61 ms).
+static int g_sell_wide = -1, g_sell_wide_mm = -1;
+static inline bool sell_wide_at(const Csr& a, int width) {
+  return width > 0 && a.nslice > 0 && a.nlong == 0 && a.sl_nnz >= (int64_t)64 * width * a.nslice;
+}
 static inline bool sell_wide(const Csr& a) {
   if (g_sell_wide < 0) g_sell_wide = getenv("GENEO_SELL_WIDE") ? atoi(getenv("GENEO_SELL_WIDE")) : 16;
-  return g_sell_wide > 0 && a.nslice > 0 && a.nlong == 0 && a.sl_nnz >= (int64_t)64 * g_sell_wide * a.nslice;
+  return sell_wide_at(a, g_sell_wide);
+}
+static inline bool sell_wide_mm(const Csr& a) {
+  if (g_sell_wide_mm < 0) g_sell_wide_mm = getenv("GENEO_SELL_WIDE_MM") ? atoi(getenv("GENEO_SELL_WIDE_MM")) : 9;
+  return sell_wide_at(a, g_sell_wide_mm);
 }
 template <int EPI>
 static void spmv_wide_launch(const Csr& a, const double* x, double* y, const double* b, double* z, const double* dinv,
@@ -1188,6 +1232,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
     y[r] = z[r] + sum;
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+  } else if (EPI == EPI_POST) {
+    y[r] = z[r] + w * dinv[r] * b[r] + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
     z[r] = w * dinv[r] * bb;
@@ -1219,6 +1265,7 @@ void spmv_fused_lp(const Csr& a, int epi, const double* x, double* y, const doub
     case EPI_RES: spmv_lp_launch<EPI_RES>(a, x, y, b, z, dinv, w); break;
     case EPI_ADD: spmv_lp_launch<EPI_ADD>(a, x, y, b, z, dinv, w); break;
     case EPI_JAC: spmv_lp_launch<EPI_JAC>(a, x, y, b, z, dinv, w); break;
+    case EPI_POST: spmv_lp_launch<EPI_POST>(a, x, y, b, z, dinv, w); break;
     case EPI_PRE: spmv_lp_launch<EPI_PRE>(a, x, y, b, z, dinv, w); break;
     default: throw std::runtime_error("spmv_fused_lp: unknown epilogue");
   }
@@ -1254,6 +1301,8 @@ __global__ __launch_bounds__(256) void k_spmv_vec(int n, const int* __restrict__
     y[r] = z[r] + s;
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - s);
+  } else if (EPI == EPI_POST) {
+    y[r] = z[r] + w * dinv[r] * b[r] + s;
   } else {
     const double bb = b[r];
     z[r] = w * dinv[r] * bb;
@@ -1505,6 +1554,8 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
           Y[r * ldy + j] = Z[r * ldz + j] + sacc;
         } else if (EPI == EPI_JAC) {
           Y[r * ldy + j] = X[r * ldx + j] + w * dinv[r] * (B[r * ldb + j] - sacc);
+        } else if (EPI == EPI_POST) {
+          Y[r * ldy + j] = Z[r * ldz + j] + w * dinv[r] * B[r * ldb + j] + sacc;
         } else {  // EPI_PRE: X = B, pre = dinv
           const double bb = B[r * ldb + j];
           Z[r * ldz + j] = w * dinv[r] * bb;
@@ -1624,6 +1675,9 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
         } else if (EPI == EPI_JAC) {
           out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
                 (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+        } else if (EPI == EPI_POST) {
+          out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
+                (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
         } else {  // EPI_PRE: X = B, pre = dinv
           const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
           *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
@@ -1708,6 +1762,9 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
     } else if (EPI == EPI_JAC) {
       out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
             (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+    } else if (EPI == EPI_POST) {
+      out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
+            (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
     } else {  // EPI_PRE: X = B, pre = dinv
       const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
       *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
@@ -1738,7 +1795,7 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
   if (m != 16 && m != 32 && m != 64) return false;
   if ((ldx | ldy | ldb | ldz) & 1) return false;
   if (!aligned16(X) || !aligned16(Y) || !aligned16(B) || !aligned16(Z)) return false;
-  if (sell_wide(a)) {
+  if (sell_wide_mm(a)) {
     const int per = (a.nslice + 7) / 8;
 #define SELLW(L)                                                                                                           \
   hipLaunchKernelGGL((k_spmm_sell_wide<L, EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
@@ -1822,7 +1879,7 @@ static void spmm_fused_t(const Csr& a, const double* X, int ldx, double* Y, int 
   const double* pre = (EPI == EPI_PRE && !a.col_scaled) ? dinv : nullptr;
   // + the epilogue's block reads / writes: RES, ADD one more block in, JAC two, PRE one more out
   ProfScope prof(PROF_SPMM, a.fine && m >= 16,
-                 (double)a.nnz * 12.0 + (double)a.n * 4.0 + (16.0 + (EPI == EPI_JAC ? 16.0 : 8.0)) * m * (double)a.n,
+                 (double)a.nnz * 12.0 + (double)a.n * 4.0 + (16.0 + ((EPI == EPI_JAC || EPI == EPI_POST) ? 16.0 : 8.0)) * m * (double)a.n,
                  2.0 * (double)a.nnz * m);
   if (spmm_sell_launch<EPI>(a, Xin, ldin, Y, ldy, m, pre, nullptr, B, ldb, Z, ldz, dinv, w)) return;
   if (m <= 16) {
@@ -1846,6 +1903,7 @@ void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int 
     case EPI_RES: spmm_fused_t<EPI_RES>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
     case EPI_ADD: spmm_fused_t<EPI_ADD>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
     case EPI_JAC: spmm_fused_t<EPI_JAC>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
+    case EPI_POST: spmm_fused_t<EPI_POST>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
     case EPI_PRE: spmm_fused_t<EPI_PRE>(a, X, ldx, Y, ldy, m, B, ldb, Z, ldz, dinv, w); break;
     default: throw std::runtime_error("spmm_fused: unknown epilogue");
   }

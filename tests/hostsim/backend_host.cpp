@@ -110,6 +110,19 @@ Csr csr_scaled_alias(const Csr& a, const double* rs, const double* cs, bool col_
     for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) b.val[k] = (rs ? rs[r] : 1.0) * a.val[k] * (cs ? cs[a.col[k]] : 1.0);
   return b;
 }
+bool post_matrix(Csr& ap, const Csr& p, const double* dinv, double w) {
+  for (int i = 0; i < ap.n; ++i) {
+    int found = 0;
+    for (int k = ap.rowptr[i]; k < ap.rowptr[i + 1]; ++k) {
+      double v = -w * dinv[i] * ap.val[k];
+      for (int q = p.rowptr[i]; q < p.rowptr[i + 1]; ++q)
+        if (p.col[q] == ap.col[k]) { v += p.val[q]; ++found; break; }
+      ap.val[k] = v;
+    }
+    if (found != p.rowptr[i + 1] - p.rowptr[i]) return false;
+  }
+  return true;
+}
 // no single-precision companions on the test backend: the V-cycle takes its FP64 path
 bool csr_make_lp(Csr&, const Csr*) { return false; }
 void csr_free_lp(Csr&) {}
@@ -166,6 +179,7 @@ void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int 
       if (epi == EPI_RES) y = B[(int64_t)i * ldb + j] - s;
       else if (epi == EPI_ADD) y = Z[(int64_t)i * ldz + j] + s;
       else if (epi == EPI_JAC) y = X[(int64_t)i * ldx + j] + w * dinv[i] * (B[(int64_t)i * ldb + j] - s);
+      else if (epi == EPI_POST) y = Z[(int64_t)i * ldz + j] + w * dinv[i] * B[(int64_t)i * ldb + j] + s;
       else {
         const double bb = B[(int64_t)i * ldb + j];
         Z[(int64_t)i * ldz + j] = w * dinv[i] * bb;
