@@ -424,7 +424,11 @@ def main():
                                       if size == 1 else
                                       "N>1: the metric's configuration, 184^3 DoF and one subdomain per GPU (N=8: 368^3 = 49.8 M)"),
                        "grid": n, "dof": n ** 3, "subdomains": nb, "subdomains_per_gpu": spg, "overlap": args.overlap,
-                       "transport": comm_name},
+                       "transport": comm_name,
+                       "inner_solver": "local solves = AMG-PCG to -dls1_ksp_rtol %g in FP64 (the V-cycle streams float copies of "
+                                       "its level matrices, -dls1_amg_precision single: FP64 arithmetic and vectors)" % args.dls1_rtol,
+                       "allocator": "device blocks are cached across set-ups (the timed steps re-set-up one PC: no hipMalloc "
+                                    "inside them after the warm-up step)"},
             "setup_s": setup_s, "solve_s": solve_s, "setup_plus_solve_s": setup_s + solve_s,
             "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
             "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],

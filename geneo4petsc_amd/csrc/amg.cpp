@@ -369,7 +369,7 @@ void AmgDevice::free_all() {
     bk::csr_free(L.Acs);
     bk::csr_free(L.M);
     if (L.own_A) bk::csr_free(L.A);
-    else bk::csr_free_lp(L.A);    // the companion of a borrowed matrix is ours
+    else if (L.own_lp_A) bk::csr_free_lp(L.A);    // the companion of a borrowed matrix, when it was made here
     bk::csr_free(L.P);
     bk::csr_free(L.R);
     bk::dfree(L.dinv); bk::dfree(L.b); bk::dfree(L.x); bk::dfree(L.r); bk::dfree(L.d); bk::dfree(L.ad);
@@ -435,7 +435,9 @@ void AmgDevice::make_single() {
   for (Lvl& L : lv) {
     if (!L.fused) continue;
     // the level-0 matrix may be borrowed: the companion then hangs off OUR copy of the descriptor
+    const bool had = bk::csr_has_lp(L.A);
     if (bk::csr_make_lp(L.A)) ++nlp;
+    L.own_lp_A = !L.own_A && !had && bk::csr_has_lp(L.A);
     if (L.Acs.n && bk::csr_make_lp(L.Acs, &L.A)) ++nlp;
     if (L.P.n && bk::csr_make_lp(L.P)) ++nlp;
     if (L.R.n && bk::csr_make_lp(L.R)) ++nlp;

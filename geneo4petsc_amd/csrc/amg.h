@@ -68,6 +68,7 @@ class AmgDevice {
     int n = 0;
     double rho = 2.0;
     bool own_A = true;
+    bool own_lp_A = false;    // the single-precision companion of a BORROWED level-0 matrix was made here (else its owner made it)
     bool fused = false;       // A and P have no long-row remainder: fused-epilogue cycle
   };
   std::vector<Lvl> lv;

@@ -577,6 +577,9 @@ int PC::setup(const double* b_dev) {
   lap("A_Dir blockdiag (joined)");
   dirL = upload_host(h_dirL);
   dirL.fine = true;
+  // 16-bit column offsets per slice (+ float values for the V-cycle): the FP64 SpMV of the local solves then reads
+  // 10 bytes per entry instead of 12; the level-1 hierarchy borrows this companion instead of making its own
+  bk::csr_make_lp(dirL);
   lap("upload A_Dir");
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {

@@ -200,6 +200,21 @@ def test_single_precision_companion(lib, n, per_row, kind, half_width):
         lib.GeneoSetSpmvKind(1)
 
 
+def test_spmv_with_16bit_column_offsets(lib):
+    """Once a matrix has its companion, the FP64 SpMV of a large matrix reads the companion's 16-bit column offsets
+    (10 bytes per entry) with the FP64 values: same result as the 32-bit path to rounding."""
+    from geneo4petsc_amd.pc import Spmv
+    n = 700000
+    a = _band_csr(n, 6, 20000, 51)
+    x = np.random.default_rng(52).random(n) - 0.5
+    h = Spmv(a, lib)
+    y32 = h.apply(x)
+    h.fused_single(0, X=x)            # builds the companion
+    y16 = h.apply(x)
+    np.testing.assert_allclose(y32, a @ x, rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(y16, y32)     # same entries in the same order: bitwise
+
+
 def test_single_precision_companion_keeps_32bit_columns_for_wide_slices(lib):
     """A slice whose columns span more than 65535 keeps its 32-bit columns (float values only)."""
     from geneo4petsc_amd.pc import Spmv
