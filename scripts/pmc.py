@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"k_spmv_sell": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96",
+KERNELS = {"k_spmv_sell<": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96",
            "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32": "lobpcg_update32"}
 CALIB = 40_000_000
 
@@ -48,6 +48,10 @@ def work(argv):
     y = DeviceVector(lib, rows)
     X = DeviceVector.from_host(lib, np.random.default_rng(1).random(rows * 96))
     Y = DeviceVector(lib, rows * 96)
+    # the solver's fine matrix carries 16-bit column offsets (its single-precision companion): build them first so that
+    # the SpMV measured here is the variant the local solves launch (10 B per entry)
+    if os.environ.get("PMC_SPMV_32BIT_COLUMNS", "0") != "1":
+        lib.GeneoSpmvFusedSingle(h.h, 0, x.ptr, y.ptr, None, None, None, C.c_double(0.0))
     for _ in range(6):
         evict()
         lib.GeneoSpmvApply(h.h, x.ptr, y.ptr)
