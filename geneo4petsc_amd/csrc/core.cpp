@@ -2405,12 +2405,25 @@ struct ConvTest {
   }
 };
 
+// Device vectors of a Krylov driver: released on every way out, a throwing callback (halo exchange, all-reduce) included
+struct DeviceVectors {
+  std::vector<double*> v;
+  double* get(int n) {
+    v.push_back((double*)bk::alloc(sizeof(double) * std::max(1, n)));
+    return v.back();
+  }
+  ~DeviceVectors() {
+    for (double* p : v) bk::dfree(p);
+  }
+};
+
 // KSPSolve_CG (PETSc cg.c), KSP_NORM_PRECONDITIONED
 int PC::solve_cg(const double* b, double* x, KspResult* res) {
   const int n = n_owned();
-  auto dv = [&](void) { return (double*)bk::alloc(sizeof(double) * std::max(1, n)); };
+  DeviceVectors bufs;
+  auto dv = [&](void) { return bufs.get(n); };
   double *r = dv(), *z = dv(), *p = dv(), *w = dv();
-  auto done = [&](int rc) { bk::dfree(r); bk::dfree(z); bk::dfree(p); bk::dfree(w); return rc; };
+  auto done = [&](int rc) { return rc; };
   ConvTest conv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
   residual_history.clear();
   if (opt.ksp_guess_nonzero) {
@@ -2461,13 +2474,10 @@ int PC::solve_gmres(const double* b, double* x, KspResult* res) {
   const int n = n_owned();
   const int m = std::max(1, opt.ksp_restart);
   std::vector<double*> V;
-  auto dvec = [&]() { return (double*)bk::alloc(sizeof(double) * std::max(1, n)); };
+  DeviceVectors bufs;
+  auto dvec = [&]() { return bufs.get(n); };
   double *t = dvec(), *w = dvec();
-  auto done = [&](int rc) {
-    for (double* v : V) bk::dfree(v);
-    bk::dfree(t); bk::dfree(w);
-    return rc;
-  };
+  auto done = [&](int rc) { return rc; };
   ConvTest conv{opt.ksp_rtol, opt.ksp_atol, opt.ksp_dtol};
   residual_history.clear();
   res->its = 0;
