@@ -296,7 +296,12 @@ def main():
         if staged:
             comm, comm_name = gcomm.StagedComm(plan, lib), "staged (gloo, host copies)"
         elif args.comm == "rccl":
-            comm, comm_name = gcomm.RcclComm(plan, lib, dist, torch.device("cuda", local_rank)), "rccl (C++ transport in libgeneopc)"
+            try:
+                comm, comm_name = gcomm.RcclComm(plan, lib, dist, torch.device("cuda", local_rank)), "rccl (C++ transport in libgeneopc)"
+            except RuntimeError as e:      # raised on every rank together (comm.RcclComm agrees first): same fallback everywhere
+                if rank == 0:
+                    print("bench.py: %s -- falling back to the torch.distributed transport" % e, file=sys.stderr, flush=True)
+                comm, comm_name = gcomm.TorchComm(plan, torch.device("cuda", local_rank)), "torch.distributed (nccl backend; the C++ RCCL transport failed to start)"
         else:
             comm, comm_name = gcomm.TorchComm(plan, torch.device("cuda", local_rank)), "torch.distributed (nccl backend)"
     prep_s = time.perf_counter() - t_prep

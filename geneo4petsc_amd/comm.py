@@ -121,14 +121,33 @@ class RcclComm:
         import ctypes as C
         self.lib, self.plan, self.error = lib, plan, None
         ida = C.create_string_buffer(128)
+        err = None
         if plan.rank == 0 and lib.GeneoRcclUniqueId(ida):
-            raise RuntimeError(lib.GeneoRcclGetError().decode())
-        if plan.size > 1:
-            import torch
-            t = torch.tensor(list(ida.raw), dtype=torch.uint8, device=device if device is not None else "cpu")
-            dist.broadcast(t, 0)
-            ida = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+            err = lib.GeneoRcclGetError().decode()
         self.h = C.c_void_p()
+        if plan.size > 1:
+            # Every step is agreed on by all ranks before anyone raises: a rank that fails alone (RCCL not loadable,
+            # communicator not created) must not leave the others waiting in a collective -- the caller can then fall
+            # back to another transport on ALL ranks (bench.py does).
+            import torch
+            dev = device if device is not None else "cpu"
+            t = torch.tensor([0 if err else 1] + list(ida.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            raw = t.cpu().tolist()
+            if raw[0] == 0:
+                raise RuntimeError("RCCL transport: rank 0 could not create the unique id" + (": " + err if err else ""))
+            ida = C.create_string_buffer(bytes(raw[1:]), 128)
+            rc = lib.GeneoRcclCreate(ida, int(plan.rank), int(plan.size), C.byref(self.h))
+            msg = lib.GeneoRcclGetError().decode() if rc else ""
+            ok = torch.tensor([0 if rc else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if not rc:
+                    lib.GeneoRcclDestroy(C.byref(self.h))
+                raise RuntimeError("RCCL transport: communicator creation failed on at least one rank" + (": " + msg if msg else ""))
+            return
+        if err:
+            raise RuntimeError(err)
         if lib.GeneoRcclCreate(ida, int(plan.rank), int(plan.size), C.byref(self.h)):
             raise RuntimeError(lib.GeneoRcclGetError().decode())
 

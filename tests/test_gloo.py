@@ -46,3 +46,15 @@ def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     assert np.linalg.norm(got["y"] - orc.apply(b)) <= 1e-9 * np.linalg.norm(orc.apply(b))
     # two iterates of the same count: to the Krylov tolerance for CG (cases.Tight: amplified rounding), 1e-7 for GMRES
     assert np.linalg.norm(got["x"] - res.x) <= (1e-6 if ksp == "cg" else 1e-7) * np.linalg.norm(res.x)
+
+
+def test_rccl_bootstrap_failure_is_collective():
+    """comm.RcclComm agrees among the ranks before raising (unique id on rank 0, then communicator creation): on this
+    GPU-less box the C++ transport cannot start, and both ranks must learn that together instead of one of them hanging
+    in the broadcast."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "rccl_bootstrap_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OUTCOME " in r.stdout
