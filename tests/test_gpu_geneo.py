@@ -171,6 +171,27 @@ def test_hub_row_falls_back_to_host_products(lib, capfd, monkeypatch):
     assert "A_Neu hierarchy (host products)" in err
 
 
+@pytest.mark.parametrize("precision", ["double", "single"])
+@pytest.mark.parametrize("post", ["1", ""])
+def test_vcycle_storage_and_form_do_not_change_the_result(lib, precision, post, monkeypatch):
+    """The local solves' V-cycle with FP64 level matrices (-dls1_amg_precision double) or their single-precision
+    companions (default), with the one-product post-smoothing (M = P - w D^-1 A P, default) or the two-launch form
+    (GENEO_AMG_NO_POST_MATRIX): the same iteration counts as the oracle and the same solution in all four, on a case
+    whose subdomains are large enough for a three-level hierarchy (20^3 in 8 subdomains, AMG inner solves)."""
+    if post:
+        monkeypatch.setenv("GENEO_AMG_NO_POST_MATRIX", post)
+    # no -geneo_cut: the threshold keeps whole multiplets (a cut inside one leaves the choice of its members, and with
+    # it the iteration count, to the eigensolver)
+    # and GMRES to 1e-6 (23 iterations): beyond ~16 iterations at this size the residual histories of two correct
+    # implementations drift apart by tens of per cent (1e-9 differences of the local solves, amplified), so a count
+    # taken at 1e-8 (32 against 31) measures that noise, not the preconditioner
+    argv = ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.2", "-ksp_type", "gmres", "-dls1_pc_type", "amg",
+            "-els2_pc_type", "amg", "-dls1_amg_precision", precision, "-amg_coarse_size", "100",
+            "-ksp_gmres_restart", "100"] + TIGHT + ["-ksp_rtol", "1e-6"]
+    _, info = cases.compare_with_oracle(lib, 20, (2, 2, 2), 2, argv, xtol=1e-6)    # two iterates at a Krylov tolerance of 1e-6
+    assert info["amg_levels"] >= 3
+
+
 def test_large_coarse_operator_blocked_cholesky(lib):
     """dimE = 312 and a 64-column LOBPCG block (192-column Gram / block update kernels); E through the blocked Cholesky."""
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "39", "-ksp_type", "cg"] + TIGHT
