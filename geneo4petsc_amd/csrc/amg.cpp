@@ -452,10 +452,10 @@ double AmgDevice::jacobi_weight(const Lvl& L) const {
 
 // The post-smoothing half of the damped-Jacobi V-cycle in one product.  With x1 = w D^-1 b and r1 = b - A x1 from the
 // zero-guess sweep (EPI_PRE) and e the coarse correction:
-//     t = x1 + P e ,  x = t + w D^-1 (b - A t)   =   x1 + w D^-1 r1 + (P - w D^-1 A P) e
+//     t = x1 + P e ,  x = t + w D^-1 (b - A t)   =   x1 + w D^-1 r1 + (P - w D^-1 A P) e   =   w D^-1 (b + r1) + M e
 // so the prolongation, the correction and the sweep cost ONE pass over M = P - w D^-1 A P (about the entries of A, and
 // it gathers the small coarse vector, not a fine one) instead of a pass over P and a pass over A with a fine gather:
-// three fine-vector passes (x1, r1 in, x out) instead of five.  A P is a by-product of the Galerkin product (device
+// three fine-vector passes (b, r1 in, x out) instead of five, and the zero-guess sweep stores r1 only.  A P is a by-product of the Galerkin product (device
 // set-up) or one more device sparse product (host set-up).  `ap` (consumed) may be null.
 void AmgDevice::make_post_matrix(Lvl& L, bk::Csr* ap, int nc) {
   const bool want = prm.smooth_degree <= 1 && L.fused && !getenv("GENEO_AMG_NO_POST_MATRIX");
@@ -666,14 +666,16 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
     const double w = jacobi_weight(L);
     const bk::Csr& Apre = L.Acs.n ? L.Acs : L.A;
     const bool vec = (m == 1 && ldb <= 1 && ldx <= 1);     // contiguous single vectors: the companions apply
-    if (vec && bk::csr_has_lp(Apre)) bk::spmv_fused_lp(Apre, bk::EPI_PRE, nullptr, L.r, B, X, L.dinv, w);
-    else bk::spmm_fused(Apre, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X, ldx, L.dinv, w);   // x = w D^-1 b ; r = b - A x
+    // with the post-smoothing matrix x1 = w D^-1 b is never read back (EPI_POST rebuilds it from b): it is not stored
+    double* X1 = L.M.n ? nullptr : X;
+    if (vec && bk::csr_has_lp(Apre)) bk::spmv_fused_lp(Apre, bk::EPI_PRE, nullptr, L.r, B, X1, L.dinv, w);
+    else bk::spmm_fused(Apre, bk::EPI_PRE, nullptr, 0, L.r, m, m, B, ldb, X1, ldx, L.dinv, w);   // x1 = w D^-1 b ; r1 = b - A x1
     if (vec && bk::csr_has_lp(L.R)) bk::spmv_lp(L.R, L.r, C0.b);
     else applyA(L.R, L.r, m, C0.b, m, m);                                                   // restrict
     cycle(l + 1, C0.b, m, C0.x, m, m);
-    if (L.M.n) {      // x = x1 + w D^-1 r1 + (P - w D^-1 A P) e, in place on X
-      if (vec && bk::csr_has_lp(L.M)) bk::spmv_fused_lp(L.M, bk::EPI_POST, C0.x, X, L.r, X, L.dinv, w);
-      else bk::spmm_fused(L.M, bk::EPI_POST, C0.x, m, X, ldx, m, L.r, m, X, ldx, L.dinv, w);
+    if (L.M.n) {      // x = w D^-1 (b + r1) + (P - w D^-1 A P) e
+      if (vec && bk::csr_has_lp(L.M)) bk::spmv_fused_lp(L.M, bk::EPI_POST, C0.x, X, L.r, const_cast<double*>(B), L.dinv, w);
+      else bk::spmm_fused(L.M, bk::EPI_POST, C0.x, m, X, ldx, m, L.r, m, const_cast<double*>(B), ldb, L.dinv, w);
       return;
     }
     if (vec && bk::csr_has_lp(L.P)) bk::spmv_fused_lp(L.P, bk::EPI_ADD, C0.x, L.d, nullptr, X, nullptr, 0.0);

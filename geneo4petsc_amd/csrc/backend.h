@@ -107,9 +107,10 @@ void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, in
 //   EPI_RES : Y = B - A X
 //   EPI_ADD : Y = Z + A X                         (prolongation + correction; Y must not alias Z or X)
 //   EPI_JAC : Y = X + w dinv .* (B - A X)         (damped-Jacobi sweep, out of place)
-//   EPI_PRE : Z = w dinv .* B ;  Y = B - A Z      (zero-guess sweep + residual; X unused)
-//   EPI_POST: Y = Z + w dinv .* B + A X           (A = P - w D^-1 A P: prolongation + correction + post-smoothing sweep
-//                                                  in one launch, see AmgDevice::cycle; Y may alias Z)
+//   EPI_PRE : Z = w dinv .* B ;  Y = B - A Z      (zero-guess sweep + residual; X unused; Z may be null: Z not stored)
+//   EPI_POST: Y = w dinv .* (Z + B) + A X         (A = P - w D^-1 A P, Z = the cycle's right-hand side b, B = the residual
+//                                                  r1 of the zero-guess sweep: prolongation + correction + post-smoothing
+//                                                  sweep in one launch, see AmgDevice::cycle)
 enum { EPI_NONE = 0, EPI_RES = 1, EPI_ADD = 2, EPI_JAC = 3, EPI_PRE = 4, EPI_POST = 5 };
 // M = P - w diag(dinv) AP, written over the values of AP (pattern(P) must be contained in pattern(AP): true for
 // AP = A P with a full diagonal in A).  Returns false (AP untouched in pattern, values undefined) when an entry of P has

@@ -1018,10 +1018,10 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
   } else if (EPI == EPI_POST) {
-    y[r] = z[r] + w * dinv[r] * b[r] + sum;
+    y[r] = w * dinv[r] * (z[r] + b[r]) + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
-    z[r] = w * dinv[r] * bb;
+    if (z) z[r] = w * dinv[r] * bb;
     y[r] = bb - w * sum;
   }
 }
@@ -1078,10 +1078,10 @@ __global__ __launch_bounds__(256) void k_spmv_sell_wide(const int64_t* __restric
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
   } else if (EPI == EPI_POST) {
-    y[r] = z[r] + w * dinv[r] * b[r] + sum;
+    y[r] = w * dinv[r] * (z[r] + b[r]) + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
-    z[r] = w * dinv[r] * bb;
+    if (z) z[r] = w * dinv[r] * bb;
     y[r] = bb - w * sum;
   }
 }
@@ -1237,10 +1237,10 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - sum);
   } else if (EPI == EPI_POST) {
-    y[r] = z[r] + w * dinv[r] * b[r] + sum;
+    y[r] = w * dinv[r] * (z[r] + b[r]) + sum;
   } else {  // EPI_PRE
     const double bb = b[r];
-    z[r] = w * dinv[r] * bb;
+    if (z) z[r] = w * dinv[r] * bb;
     y[r] = bb - w * sum;
   }
 }
@@ -1306,10 +1306,10 @@ __global__ __launch_bounds__(256) void k_spmv_vec(int n, const int* __restrict__
   } else if (EPI == EPI_JAC) {
     y[r] = x[r] + w * dinv[r] * (b[r] - s);
   } else if (EPI == EPI_POST) {
-    y[r] = z[r] + w * dinv[r] * b[r] + s;
+    y[r] = w * dinv[r] * (z[r] + b[r]) + s;
   } else {
     const double bb = b[r];
-    z[r] = w * dinv[r] * bb;
+    if (z) z[r] = w * dinv[r] * bb;
     y[r] = bb - w * s;
   }
 }
@@ -1566,10 +1566,10 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
         } else if (EPI == EPI_JAC) {
           Y[r * ldy + j] = X[r * ldx + j] + w * dinv[r] * (B[r * ldb + j] - sacc);
         } else if (EPI == EPI_POST) {
-          Y[r * ldy + j] = Z[r * ldz + j] + w * dinv[r] * B[r * ldb + j] + sacc;
+          Y[r * ldy + j] = w * dinv[r] * (Z[r * ldz + j] + B[r * ldb + j]) + sacc;
         } else {  // EPI_PRE: X = B, pre = dinv
           const double bb = B[r * ldb + j];
-          Z[r * ldz + j] = w * dinv[r] * bb;
+          if (Z) Z[r * ldz + j] = w * dinv[r] * bb;
           Y[r * ldy + j] = bb - w * sacc;
         }
       }
@@ -1687,11 +1687,11 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
           out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
                 (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
         } else if (EPI == EPI_POST) {
-          out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
-                (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
+          out = (w * dinv[r]) * (*reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
+                                 *reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
         } else {  // EPI_PRE: X = B, pre = dinv
           const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
-          *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
+          if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
           out = bb - w * a2;
         }
         __builtin_nontemporal_store(out, reinterpret_cast<d2*>(Y + r * ldy + 2 * q));
@@ -1774,11 +1774,11 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
       out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
             (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
     } else if (EPI == EPI_POST) {
-      out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
-            (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
+      out = (w * dinv[r]) * (*reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
+                             *reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
     } else {  // EPI_PRE: X = B, pre = dinv
       const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
-      *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
+      if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
       out = bb - w * a2;
     }
     *reinterpret_cast<d2*>(Y + r * ldy + 2 * q) = out;

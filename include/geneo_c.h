@@ -256,7 +256,7 @@ PetscErrorCode GeneoSpmmTime(GeneoSpmv h, const double* X_dev, int ldx, double* 
                              const double* pre_dev, const double* post_dev, int reps, double* ms_avg);
 /* multigrid epilogues fused into the SpMV (m = 1) / SpMM launch, row-major n x m blocks:
  *   epi 1: Y = B - A X      2: Y = Z + A X      3: Y = X + w dinv.*(B - A X)      4: Z = w dinv.*B, Y = B - A Z
- *   epi 5: Y = Z + w dinv.*B + A X   (prolongation + correction + post-smoothing sweep in one product) */
+ *   epi 5: Y = w dinv.*(Z + B) + A X (prolongation + correction + post-smoothing sweep in one product) */
 PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, int m, const double* B_dev,
                               double* Z_dev, const double* dinv_dev, double w);
 /* the single-vector launches (m = 1; epi 0: Y = A X) reading the matrix's single-precision companion -- float values,

@@ -179,10 +179,10 @@ void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int 
       if (epi == EPI_RES) y = B[(int64_t)i * ldb + j] - s;
       else if (epi == EPI_ADD) y = Z[(int64_t)i * ldz + j] + s;
       else if (epi == EPI_JAC) y = X[(int64_t)i * ldx + j] + w * dinv[i] * (B[(int64_t)i * ldb + j] - s);
-      else if (epi == EPI_POST) y = Z[(int64_t)i * ldz + j] + w * dinv[i] * B[(int64_t)i * ldb + j] + s;
+      else if (epi == EPI_POST) y = w * dinv[i] * (Z[(int64_t)i * ldz + j] + B[(int64_t)i * ldb + j]) + s;
       else {
         const double bb = B[(int64_t)i * ldb + j];
-        Z[(int64_t)i * ldz + j] = w * dinv[i] * bb;
+        if (Z) Z[(int64_t)i * ldz + j] = w * dinv[i] * bb;
         y = bb - w * s;
       }
     }

@@ -130,7 +130,7 @@ def test_fused_multigrid_epilogues(lib, m, density):
     y, z = h.fused(4, B=B, dinv=dinv, w=w)
     np.testing.assert_allclose(z, w * d * B, **tol)
     np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
-    np.testing.assert_allclose(h.fused(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], Z + w * d * B + a @ X, **tol)   # EPI_POST
+    np.testing.assert_allclose(h.fused(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], w * d * (Z + B) + a @ X, **tol)   # EPI_POST
 
 
 @pytest.mark.parametrize("n,per_row", [(5000, 30), (8200, 22), (640, 45)])
@@ -163,7 +163,7 @@ def test_wide_slice_kernels(lib, m, n, per_row):
         y, z = h.fused(4, B=B, dinv=dinv, w=w)
         np.testing.assert_allclose(z, w * d * B, **tol)
         np.testing.assert_allclose(y, B - a @ (w * d * B), **tol)
-        np.testing.assert_allclose(h.fused(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], Z + w * d * B + a @ X, **tol)
+        np.testing.assert_allclose(h.fused(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], w * d * (Z + B) + a @ X, **tol)
     finally:
         lib.GeneoSetSpmvKind(1)
 
@@ -195,7 +195,7 @@ def test_single_precision_companion(lib, n, per_row, kind, half_width):
         y, z = h.fused_single(4, B=B, dinv=dinv, w=w)
         np.testing.assert_allclose(z, w * dinv * B, **tol)
         np.testing.assert_allclose(y, B - a32 @ (w * dinv * B), **tol)
-        np.testing.assert_allclose(h.fused_single(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], Z + w * dinv * B + a32 @ X, **tol)
+        np.testing.assert_allclose(h.fused_single(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0], w * dinv * (Z + B) + a32 @ X, **tol)
     finally:
         lib.GeneoSetSpmvKind(1)
 
