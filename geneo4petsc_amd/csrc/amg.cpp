@@ -146,20 +146,37 @@ static HostCsr spgemm(const HostCsr& a, const HostCsr& b, int ncols_b) {
   return c;
 }
 
-// Vanek-style aggregation inside one diagonal block [r0, r1): returns #aggregates, agg[i] local ids
-static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& agg) {
+// Vanek-style aggregation inside one diagonal block [r0, r1): returns #aggregates, agg[i] local ids.
+// theta > 0: only STRONG connections |a_ij| >= theta sqrt(a_ii a_jj) tie nodes together (Vanek, Mandel, Brezina 1996).
+static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& agg, double theta = 0.0) {
   int na = 0;
   for (int i = r0; i < r1; ++i) agg[i] = -1;
-  for (int i = r0; i < r1; ++i) {  // phase 1: a free node whose whole neighbourhood is free seeds an aggregate
+  std::vector<double> dg;
+  if (theta > 0.0) {
+    dg.assign(r1 - r0, 0.0);
+    for (int i = r0; i < r1; ++i)
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
+        if (a.col[k] == i) dg[i - r0] = std::fabs(a.val[k]);
+  }
+  const double t2 = theta * theta;
+  auto strong = [&](int i, int k) {
+    const double v = a.val[k];
+    if (v == 0.0) return false;
+    if (theta <= 0.0) return true;
+    const int j = a.col[k];
+    if (j < r0 || j >= r1) return false;
+    return v * v >= t2 * dg[i - r0] * dg[j - r0];
+  };
+  for (int i = r0; i < r1; ++i) {  // phase 1: a free node whose whole (strong) neighbourhood is free seeds an aggregate
     if (agg[i] >= 0) continue;
     bool ok = true;
     for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
       const int j = a.col[k];
-      if (j != i && a.val[k] != 0.0 && agg[j] >= 0) { ok = false; break; }
+      if (j != i && strong(i, k) && agg[j] >= 0) { ok = false; break; }
     }
     if (!ok) continue;
     for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
-      if (a.val[k] != 0.0) agg[a.col[k]] = na;
+      if (strong(i, k)) agg[a.col[k]] = na;
     agg[i] = na++;
   }
   std::vector<int> join(r1 - r0, -1);
@@ -179,6 +196,16 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
   for (int i = r0; i < r1; ++i)  // phase 3: isolated nodes
     if (agg[i] < 0) agg[i] = na++;
   return na;
+}
+
+// Strength threshold of level l.  Level 0 keeps every entry (the operators handed in are mesh matrices: an M-matrix
+// stencil has no weak entries worth dropping, and a high-contrast one is the eigensolver's business); from level 1 on
+// the Galerkin operators of smoothed aggregation carry many weak far couplings (27-point-like rows of 31 entries on a
+// 7-point problem) and distance-1 aggregates over ALL of them coarsen 44-fold -- an interpolation the next level
+// cannot support.  theta_l = theta 0.5^l (Vanek, Mandel, Brezina).
+static double amg_strength(const AmgParams& prm, int level) {
+  if (level < 1 || prm.strength <= 0.0) return 0.0;
+  return prm.strength * std::pow(0.5, level);
 }
 
 static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
@@ -289,7 +316,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
       std::vector<int> nagg(nsub, 0);
       std::vector<std::thread> th;
       for (int s = 0; s < nsub; ++s)
-        th.emplace_back([&, s]() { nagg[s] = aggregate_block(LA, L.suboff[s], L.suboff[s + 1], agg); });
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(LA, L.suboff[s], L.suboff[s + 1], agg, amg_strength(prm, (int)levels.size() - 1)); });
       for (auto& x : th) x.join();
       for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
       for (int s = 0; s < nsub; ++s)
@@ -541,7 +568,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
       std::vector<int> nagg(nsub, 0);
       std::vector<std::thread> th;
       for (int s = 0; s < nsub; ++s)
-        th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], agg); });
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], agg, amg_strength(prm, l)); });
       for (auto& x : th) x.join();
       for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
       for (int s = 0; s < nsub; ++s)

@@ -18,6 +18,7 @@ struct AmgParams {
   int coarse_size = 600;      // stop coarsening when every subdomain block is at most this large
   int smooth_degree = 1;      // Chebyshev-Jacobi smoother degree (1 = damped Jacobi)
   double smooth_ratio = 4.0;  // smoothing interval [rho/ratio, 1.1 rho]
+  double strength = 0.0;      // aggregation on levels >= 1 ties only strong connections |a_ij| >= strength 0.5^l sqrt(a_ii a_jj); 0 = all
   bool single = false;        // single-vector V-cycles read single-precision companions of the level matrices (FP64 arithmetic)
 };
 

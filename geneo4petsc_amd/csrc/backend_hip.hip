@@ -3248,9 +3248,16 @@ __global__ __launch_bounds__(256) void k_dense_sym_apply(const int* __restrict__
   for (int e = threadIdx.x; e < nrows * m; e += 256) {
     const int rr = e % nrows, j = e / nrows;   // consecutive threads -> consecutive rows (coalesced A reads)
     const int i = row0 - s0 + rr;
-    double acc = 0.0;
-    for (int k = 0; k < ns; ++k) acc += A[(int64_t)k * ns + i] * B[(int64_t)(s0 + k) * ldb + j];
-    X[(int64_t)(row0 + rr) * ldx + j] = acc;
+    // eight independent partial sums: the loads of eight columns are in flight together (the block is a few dozen
+    // columns wide and one thread walks all of them: with a single chain the launch is 56 load latencies long)
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int k = 0;
+    for (; k + 8 <= ns; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += A[(int64_t)(k + u) * ns + i] * B[(int64_t)(s0 + k + u) * ldb + j];
+    }
+    for (; k < ns; ++k) a8[0] += A[(int64_t)k * ns + i] * B[(int64_t)(s0 + k) * ldb + j];
+    X[(int64_t)(row0 + rr) * ldx + j] = ((a8[0] + a8[4]) + (a8[1] + a8[5])) + ((a8[2] + a8[6]) + (a8[3] + a8[7]));
   }
 }
 void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, const double* B, int ldb, double* X,

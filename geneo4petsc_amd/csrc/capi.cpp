@@ -159,6 +159,7 @@ const char* usageGenEO_c(void) {
          "  -els2_cheb_degree / -els2_cheb_ratio\n"
          "  -dls1_ksp_rtol / -dls1_ksp_max_it / -dls1_pc_type amg|jacobi   local solves (batched PCG)\n"
          "  -dls1_amg_precision single|double   storage of the matrices its V-cycle reads (arithmetic and vectors: double)\n"
+         "  -dls1_amg_strength T / -els2_amg_strength T   aggregation from level 1 on ties |a_ij| >= T 0.5^l sqrt(a_ii a_jj) only\n"
          "  -amg_coarse_size / -amg_smooth_degree / -amg_smooth_ratio / -amg_max_levels\n"
          "  -ksp_type cg|gmres -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart\n\n";
 }

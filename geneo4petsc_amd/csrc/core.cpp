@@ -145,6 +145,8 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
     o.els2_pc = value;
     return "";
   }
+  if (key == "-dls1_amg_strength") return dbl(o.dls1_amg_strength);
+  if (key == "-els2_amg_strength") return dbl(o.els2_amg_strength);
   if (key == "-dls1_amg_precision") {
     if (value != "single" && value != "double") return "unsupported -dls1_amg_precision " + value;
     o.dls1_amg_single = (value == "single");
@@ -500,6 +502,7 @@ int PC::finish_amg1() {
     // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
     AmgParams ap1 = amg_params(opt);
     ap1.single = opt.dls1_amg_single;
+    ap1.strength = opt.dls1_amg_strength;
     amg1->upload(p->res.levels, p->res.cinv, p->res.cbase, ap1,
                  (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
     info.amg_levels = amg1->nlevels();
@@ -638,9 +641,14 @@ int PC::setup(const double* b_dev) {
     auto ta = clk::now();
     pend1.reset(want1 ? new Amg1Pending() : nullptr);
     if (want1) pend1->mat = std::move(h_dirL);
-    auto start1 = [this, ap]() {
+    AmgParams ap1h = ap;                      // the level-1 hierarchy (local solves): its own aggregation strength
+    ap1h.strength = opt.dls1_amg_strength;
+    AmgParams apN = ap;                       // the A_Neu hierarchy (LOBPCG preconditioner)
+    apN.strength = opt.els2_amg_strength;
+    auto start1 = [this, ap1h]() {
       Amg1Pending* pp = pend1.get();
       const std::vector<int> so = suboff;
+      const AmgParams ap = ap1h;
       pp->th = std::thread([pp, so, ap]() {
         auto t0 = clk::now();
         try {
@@ -659,11 +667,11 @@ int PC::setup(const double* b_dev) {
       try {
         amgN = new AmgDevice();
         bool built = false;
-        if (!getenv("GENEO_AMG_HOST")) built = amgN->build_on_device(h_neuL, suboff, ap, eig_block_max(), &neuL);
+        if (!getenv("GENEO_AMG_HOST")) built = amgN->build_on_device(h_neuL, suboff, apN, eig_block_max(), &neuL);
         if (!built) {
           AmgHostResult rN;
-          amg_setup_host(h_neuL, suboff, ap, rN.levels, rN.cinv, rN.cbase);
-          amgN->upload(rN.levels, rN.cinv, rN.cbase, ap, eig_block_max(), &neuL);
+          amg_setup_host(h_neuL, suboff, apN, rN.levels, rN.cinv, rN.cbase);
+          amgN->upload(rN.levels, rN.cinv, rN.cbase, apN, eig_block_max(), &neuL);
         }
         info.amg_levels = amgN->nlevels();
         info.amg_operator_complexity = amgN->operator_complexity();
