@@ -835,7 +835,8 @@ void PC::local_solve(double* wL) {
   std::vector<double> sc((size_t)8 * std::max(1, ns));
   int it = 0;
   int parity = 0;
-  const int check = std::max(1, use_amg ? std::min(4, opt.dls1_check) : opt.dls1_check);
+  static const int amg_check = getenv("GENEO_DLS1_AMG_CHECK") ? atoi(getenv("GENEO_DLS1_AMG_CHECK")) : 4;
+  const int check = std::max(1, use_amg ? std::min(amg_check, opt.dls1_check) : opt.dls1_check);
   bool done = false;
   // One chunk = `check` PCG iterations with device-resident scalars (~18 small launches each with the
   // fused V-cycle): launch-bound, so the chunk is captured once into a HIP graph and replayed.  An even

@@ -9,7 +9,7 @@ for st in "${steps[@]}"; do
   st=$(echo "$st" | sed 's/^ *//;s/ *$//')
   [ -z "$st" ] && continue
   echo "=== $st"
-  eval "env $(echo "$st" | grep -oE '^([A-Z_]+=[^ ]+ )*') bash $R/scripts/gpu.sh $(echo "$st" | sed -E 's/^([A-Z_]+=[^ ]+ )*//')"
+  eval "env $(echo "$st" | grep -oE '^([A-Z][A-Z0-9_]*=[^ ]+ )*') bash $R/scripts/gpu.sh $(echo "$st" | sed -E 's/^([A-Z][A-Z0-9_]*=[^ ]+ )*//')"
   rc=$?
   echo "=== exit $rc"
   [ $rc -gt $worst ] && worst=$rc
