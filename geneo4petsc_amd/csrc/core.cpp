@@ -212,9 +212,10 @@ PC::~PC() { free_all(); }
 
 void PC::free_all() {
   pend1.reset();
-  if (cg_graph) bk::graph_destroy(cg_graph);
-  cg_graph = nullptr;
+  for (auto& kv : cg_graphs) bk::graph_destroy(kv.second);
+  cg_graphs.clear();
   cg_graph_failed = false;
+  cg_long_len = 0;
   delete amg1;
   delete amgN;
   amg1 = amgN = nullptr;
@@ -838,11 +839,12 @@ void PC::local_solve(double* wL) {
   static const int amg_check = getenv("GENEO_DLS1_AMG_CHECK") ? atoi(getenv("GENEO_DLS1_AMG_CHECK")) : 4;
   const int check = std::max(1, use_amg ? std::min(amg_check, opt.dls1_check) : opt.dls1_check);
   bool done = false;
-  // One chunk = `check` PCG iterations with device-resident scalars (~18 small launches each with the
-  // fused V-cycle): launch-bound, so the chunk is captured once into a HIP graph and replayed.  An even
-  // chunk length brings the rz parity back to 0, which makes every chunk the same launch sequence.
-  auto chunk = [&]() {
-    for (int k = 0; k < check; ++k) {
+  // One chunk = `len` PCG iterations with device-resident scalars (~19 small launches each with the fused V-cycle):
+  // launch-bound, so a chunk is captured once per length into a HIP graph and replayed.  An even chunk length brings
+  // the rz parity back to 0, which makes every chunk of that length the same launch sequence.  Converged subdomains
+  // freeze themselves on the device (k_cg_flag), so a chunk may run past a subdomain's convergence.
+  auto chunk = [&](int len) {
+    for (int k = 0; k < len; ++k) {
       bk::spmv(dirL, d_cg_p, d_cg_q);
       bk::seg_pap(ch, d_cg_p, d_cg_q);
       bk::cg_update(ch, d_cg_sc, parity, x, d_cg_r, d_cg_z, d_cg_p, d_cg_q, dinv);
@@ -854,33 +856,54 @@ void PC::local_solve(double* wL) {
       parity ^= 1;
     }
   };
-  const bool graphable = (check % 2 == 0);
-  if (graphable && !cg_graph && !cg_graph_failed) {
+  auto graph_for = [&](int len) -> void* {
+    if (len % 2 != 0 || cg_graph_failed) return nullptr;
+    auto it_g = cg_graphs.find(len);
+    if (it_g != cg_graphs.end()) return it_g->second;
+    void* g = nullptr;
     if (bk::graph_capture_begin()) {
       try {
-        chunk();
+        chunk(len);
       } catch (...) {       // leave the capture cleanly (the stream and the capture flag are global state)
         bk::graph_capture_end();
         cg_graph_failed = true;
         throw;
       }
-      cg_graph = bk::graph_capture_end();
+      g = bk::graph_capture_end();
       parity = 0;
     }
-    if (!cg_graph) cg_graph_failed = true;
-  }
-  while (!done && it < opt.dls1_max_it) {
+    if (!g) cg_graph_failed = true;
+    else cg_graphs[len] = g;
+    return g;
+  };
+  // runs `len` iterations, then reads the per-subdomain flags back
+  auto run = [&](int len) {
+    void* g = graph_for(len);
     // While bench.py's in-situ kernel timer runs, every 8th chunk goes out as direct launches: HIP events cannot bracket
     // kernels inside a replayed graph (hipEventElapsedTime rejects events recorded by graph nodes), the other chunks
     // replay the graph as they do outside the benchmark.
-    const bool direct = !graphable || !cg_graph || (bk::spmv_profiling() && (cg_chunks++ % 8 == 0));
-    if (!direct) bk::graph_launch(cg_graph);
-    else chunk();
-    it += check;
+    const bool direct = !g || (bk::spmv_profiling() && (cg_chunks++ % 8 == 0));
+    if (!direct) bk::graph_launch(g);
+    else chunk(len);
+    it += len;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
     done = true;
     for (int s = 0; s < ns; ++s)
       if (sc[(size_t)s * 8 + 6] != 0.0) done = false;
+  };
+  // Every chunk boundary is a host round trip (flags D2H + graph launch: ~0.17 ms against 0.3 ms per iteration).  The
+  // solves of one set-up need almost the same number of iterations (126^3: 17 to 20), so after the first solve the
+  // others start with ONE long chunk just below that number and finish in chunks of 2.
+  static const bool adaptive = !getenv("GENEO_DLS1_FIXED_CHUNKS");
+  if (use_amg && adaptive && cg_long_len >= 8 && check % 2 == 0) {
+    run(cg_long_len);
+    while (!done && it < opt.dls1_max_it) run(2);
+  } else {
+    while (!done && it < opt.dls1_max_it) run(check);
+    if (use_amg && adaptive && done && cg_long_len == 0 && check % 2 == 0) {
+      const int len = ((it - check - 2) / 2) * 2;       // the solve needed more than it - check iterations
+      cg_long_len = len >= 8 ? len : -1;                 // -1: too short to bother
+    }
   }
   info.dls1_iterations += it;
   info.dls1_solves += 1;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "backend.h"
@@ -163,7 +164,8 @@ class PC {
   struct Amg1Pending;
   std::unique_ptr<Amg1Pending> pend1;   // level-1 hierarchy whose host set-up is still running
   int finish_amg1();
-  void* cg_graph = nullptr;    // HIP graph of one inner-PCG chunk (local_solve)
+  std::map<int, void*> cg_graphs;   // HIP graphs of an inner-PCG chunk, by chunk length (local_solve)
+  int cg_long_len = 0;         // length of the first chunk of a local solve once the first solve of this set-up is known (0: not yet, -1: never)
   bool cg_graph_failed = false;
   long long cg_chunks = 0;     // chunks issued so far (sampling of direct launches while the in-situ timer runs)
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
