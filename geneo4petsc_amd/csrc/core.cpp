@@ -14,6 +14,7 @@
 #include "core.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -273,6 +274,21 @@ int PC::set_intersect(int gid, int nb, const int* nonempty) {
 }
 
 // ------------------------------------------------------------------------------------ layout
+// f(r0, r1) over contiguous ranges of [0, n) on up to 16 host threads (serial below 100 000 items).  With one big
+// subdomain per rank (the N > 1 layout of bench.py) the per-subdomain loops of the set-up are single loops over
+// millions of rows.
+static void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t)>& f) {
+  int nth = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 100000) nth = 1;
+  if (nth == 1) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() { f(n * t / nth, n * (t + 1) / nth); });
+  for (auto& x : th) x.join();
+}
+
 int PC::build_layout() {
   const int ns = (int)subs.size();
   if (size == 1 && owned.empty()) {
@@ -290,23 +306,31 @@ int PC::build_layout() {
   std::sort(hmap.begin(), hmap.end());
   const bool ident = (nown == N);
   std::vector<int> l2e(nL);
-  for (int s = 0; s < ns; ++s)
-    for (size_t i = 0; i < subs[s].l2g.size(); ++i) {
-      const int g = subs[s].l2g[i];
-      int e = -1;
-      if (g < 0 || g >= N) return fail("GenEO preconditioner: global index out of range");
-      if (ident) e = g;
-      else {
-        auto it = std::lower_bound(owned.begin(), owned.end(), g);
-        if (it != owned.end() && *it == g) e = (int)(it - owned.begin());
+  for (int s = 0; s < ns; ++s) {
+    std::atomic<int> bad{0};      // 1: global index out of range, 2: neither owned nor in the halo plan
+    const std::vector<int>& l2g = subs[s].l2g;
+    const int off = suboff[s];
+    parallel_ranges((int64_t)l2g.size(), [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i) {
+        const int g = l2g[i];
+        int e = -1;
+        if (g < 0 || g >= N) { bad = 1; return; }
+        if (ident) e = g;
         else {
-          auto h = std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(g, -1));
-          if (h == hmap.end() || h->first != g) return fail("GenEO preconditioner: DOF neither owned nor in the halo plan");
-          e = nown + h->second;
+          auto it = std::lower_bound(owned.begin(), owned.end(), g);
+          if (it != owned.end() && *it == g) e = (int)(it - owned.begin());
+          else {
+            auto h = std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(g, -1));
+            if (h == hmap.end() || h->first != g) { bad = 2; return; }
+            e = nown + h->second;
+          }
         }
+        l2e[off + i] = e;
       }
-      l2e[suboff[s] + i] = e;
-    }
+    });
+    if (bad == 1) return fail("GenEO preconditioner: global index out of range");
+    if (bad == 2) return fail("GenEO preconditioner: DOF neither owned nor in the halo plan");
+  }
   // R^T as CSR over the ext space (entries in ascending local index => fixed summation order)
   std::vector<int> rt_ptr(nE + 1, 0), rt_idx(nL);
   for (int j = 0; j < nL; ++j) rt_ptr[l2e[j] + 1]++;
@@ -448,30 +472,58 @@ static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std
   const int ns = (int)mats.size();
   HostCsr b;
   b.n = suboff[ns];
-  b.rowptr.assign(b.n + 1, 0);
   std::vector<size_t> nzoff(ns + 1, 0);
   for (int s = 0; s < ns; ++s) nzoff[s + 1] = nzoff[s] + mats[s]->val.size();
-  b.col.resize(nzoff[ns]);
-  b.val.resize(nzoff[ns]);
-  auto fill = [&](int s) {
+  const bool big = nzoff[ns] > 1000000;
+  {   // the two large arrays are sized (and their pages first touched) side by side
+    std::thread tv;
+    if (big) tv = std::thread([&]() { b.val.resize(nzoff[ns]); });
+    else b.val.resize(nzoff[ns]);
+    b.col.resize(nzoff[ns]);
+    b.rowptr.assign(b.n + 1, 0);
+    if (tv.joinable()) tv.join();
+  }
+  // Row ranges of about equal size over all the matrices: with ONE subdomain per rank (the N > 1 layout of bench.py) a
+  // thread per subdomain is a single thread copying 44 M entries (184^3: 0.3 s of the set-up).
+  struct Task { int s, r0, r1; };
+  std::vector<Task> tasks;
+  const int nth = big ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+  const size_t per = std::max<size_t>(200000, nzoff[ns] / (size_t)nth + 1);
+  for (int s = 0; s < ns; ++s) {
     const HostCsr& m = *mats[s];
-    size_t pos = nzoff[s];
-    for (int i = 0; i < m.n; ++i) {
-      for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) {
-        const int cl = suboff[s] + m.col[k];
+    int r0 = 0;
+    while (r0 < m.n) {
+      int r1 = r0;
+      const size_t lim = (size_t)m.rowptr[r0] + per;
+      r1 = (int)(std::upper_bound(m.rowptr.begin() + r0, m.rowptr.begin() + m.n + 1, (int)std::min<size_t>(lim, 0x7fffffff)) -
+                 m.rowptr.begin()) - 1;
+      r1 = std::max(r0 + 1, std::min(r1, m.n));
+      tasks.push_back({s, r0, r1});
+      r0 = r1;
+    }
+  }
+  auto fill = [&](const Task& t) {
+    const HostCsr& m = *mats[t.s];
+    const int off = suboff[t.s];
+    for (int i = t.r0; i < t.r1; ++i) {
+      size_t pos = nzoff[t.s] + (size_t)m.rowptr[i];
+      for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k, ++pos) {
+        const int cl = off + m.col[k];
         b.col[pos] = colmap ? colmap[cl] : cl;
         b.val[pos] = m.val[k];
-        ++pos;
       }
-      b.rowptr[suboff[s] + i + 1] = (int)pos;
+      b.rowptr[off + i + 1] = (int)pos;
     }
   };
-  if (ns > 1 && nzoff[ns] > 1000000) {
+  if (nth > 1 && tasks.size() > 1) {
     std::vector<std::thread> th;
-    for (int s = 0; s < ns; ++s) th.emplace_back(fill, s);
+    for (int t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        for (size_t k = t; k < tasks.size(); k += nth) fill(tasks[k]);
+      });
     for (auto& x : th) x.join();
   } else {
-    for (int s = 0; s < ns; ++s) fill(s);
+    for (const Task& t : tasks) fill(t);
   }
   return b;
 }
@@ -608,13 +660,23 @@ int PC::setup(const double* b_dev) {
     double lmax = 0.0;
     for (int s = 0; s < ns; ++s) {
       const HostCsr& m = subs[s].a_neu;
-      for (int i = 0; i < m.n; ++i) {
-        double row = 0.0;
-        for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
-        const double d = dg[suboff[s] + i];
-        if (!(d > 0.0)) return fail("GenEO preconditioner: non-positive diagonal in the local Neumann matrix");
-        lmax = std::max(lmax, row / d);
-      }
+      std::mutex mu;
+      bool nonpos = false;
+      parallel_ranges(m.n, [&](int64_t i0, int64_t i1) {
+        double lm = 0.0;
+        bool np = false;
+        for (int64_t i = i0; i < i1; ++i) {
+          double row = 0.0;
+          for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
+          const double d = dg[suboff[s] + i];
+          if (!(d > 0.0)) { np = true; continue; }
+          lm = std::max(lm, row / d);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        lmax = std::max(lmax, lm);
+        nonpos = nonpos || np;
+      });
+      if (nonpos) return fail("GenEO preconditioner: non-positive diagonal in the local Neumann matrix");
     }
     cheb_lmax = lmax > 0 ? lmax : 2.0;
     if (opt.lvl2 == 2) {  // same bound for the level-1 (Robin) matrix: Chebyshev fallback of the gamma eigenproblem
