@@ -429,7 +429,14 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
     }
     if (l + 1 < levels.size()) {
       L.P = bk::csr_upload(H.P.n, H.P.rowptr.data(), H.P.col.data(), H.P.val.data());
-      L.R = bk::csr_upload(H.R.n, H.R.rowptr.data(), H.R.col.data(), H.R.val.data());
+      // R = P^T is transposed on the device (a third of this level's PCIe traffic); the host's copy is the fallback
+      // when a row of P^T exceeds the kernel's capacity
+      bool ok = !getenv("GENEO_AMG_UPLOAD_R");
+      if (ok) {
+        L.R = bk::transpose(L.P, H.R.n, &ok);
+        if (ok) bk::csr_finish(L.R);
+      }
+      if (!ok) L.R = bk::csr_upload(H.R.n, H.R.rowptr.data(), H.R.col.data(), H.R.val.data());
     }
     L.dinv = (double*)bk::alloc(sizeof(double) * std::max(1, L.n));
     bk::h2d(L.dinv, H.dinv.data(), sizeof(double) * L.n);
