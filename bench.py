@@ -74,6 +74,14 @@ def build_parser():
     ap.add_argument("--pc-args", default="", help="further options for the PC")
     ap.add_argument("--cpu-sample-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-rank-of", type=int, default=0, choices=(0, 8),
+                    help="8: ONE rank's share of the metric's configuration on this one GPU, uncontended -- subdomain "
+                         "--rank-index of the 2x2x2 decomposition of (2 n-per-gpu)^3 (default 368^3: 186^3 local rows, overlap 2, "
+                         "20 vectors) as a stand-alone problem: every communication-free phase of the set-up (SURVEY 8e: "
+                         "matrices, both hierarchies, LOBPCG, Z, the local block of E) and --apply-count applications of the "
+                         "preconditioner + local SpMV (what one PCG iteration costs this rank between two halo exchanges)")
+    ap.add_argument("--rank-index", type=int, default=0)
+    ap.add_argument("--apply-count", type=int, default=25)
     ap.add_argument("--comm", default=os.environ.get("GENEO_BENCH_COMM", "rccl"), choices=("rccl", "torch", "staged"),
                     help="N > 1 transport: rccl = C++ ncclSend/Recv + ncclAllReduce inside libgeneopc (default); "
                          "torch = torch.distributed callbacks; staged = host-staged gloo (ranks may share a GPU)")
@@ -197,6 +205,111 @@ def cpu_baseline(args, doms, lib):
     return out
 
 
+def one_rank_of(args):
+    """bench.py --one-rank-of 8: see the option's help.  The subdomain is handed to the library as a one-subdomain problem
+    in its own numbering (N = n_loc, identity map) with the REAL multiplicities, A_Neu and A_Dir of the 8-subdomain
+    decomposition: the pencil, both hierarchies, LOBPCG, Z and the local solves are exactly rank r's; the halo exchanges and
+    all-reduces (none inside these phases) are simply absent.  The `solve` leg runs exactly --apply-count PCG
+    iterations on (A_Neu, M^-1) -- one local SpMV + one preconditioner application + the dots each, the per-iteration work of
+    the rank -- not a solve of the global system."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X: the GenEO hot path has no CPU fallback")
+    torch.cuda.set_device(0)
+    from geneo4petsc_amd import _lib, decomp
+    from geneo4petsc_amd.pc import GenEOPC, DeviceVector
+    lib = _lib.load()
+    lib.GeneoSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    npg = args.n_per_gpu or 184
+    n = args.n if args.n else 2 * npg
+    parts = (2, 2, 2)
+    t_prep = time.perf_counter()
+    dom = decomp.decompose_grid_domain(n, 3, parts, args.overlap, args.rank_index)
+    nloc = len(dom.l2g)
+    b = dom.a_neu @ (np.arange(nloc, dtype=np.float64) + 1.0)
+    prep_s = time.perf_counter() - t_prep
+    argv = geneo_argv(args) + ["-ksp_max_it", str(args.apply_count), "-ksp_rtol", "1e-30", "-ksp_atol", "1e-300"]
+    pc = GenEOPC(lib)
+    pc.set_from_options(argv)
+    pc.set_sizes(nloc, 1)
+    pc.add_subdomain(0, np.arange(nloc), dom.mult, dom.a_neu, dom.a_dir)
+    bd = DeviceVector.from_host(lib, b)
+
+    def step():
+        pc.setup(bd)
+        x, its, rnorm, reason = pc.solve(bd)
+        info = pc.info()
+        x.free()
+        return its, reason, info
+
+    cold_t0 = time.perf_counter()
+    first = step()                      # the first set-up of the process: every device block comes from hipMalloc
+    torch.cuda.synchronize()
+    cold = (time.perf_counter() - cold_t0, first[2]["setupTime"], first[2]["solveTime"])
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    lib.GeneoKernelProfileStart(4, C.c_double(0.0))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.GeneoKernelProfileStop()
+    its, reason, info = last
+    kernels = kernel_table(lib, 1e3 * elapsed, args.steps)
+    ms_sum, by_sum = C.c_double(0), C.c_double(0)
+    nsamp, nlaunch = C.c_longlong(0), C.c_longlong(0)
+    lib.GeneoKernelProfileGet(0, C.byref(ms_sum), C.byref(by_sum), None, C.byref(nsamp), C.byref(nlaunch))
+    gbs = by_sum.value / max(ms_sum.value, 1e-9) * 1e-6
+    pc.setup(bd)                        # untimed step with the in-situ timer off (inner PCG chunks replay as HIP graphs)
+    xg, gits, _, _ = pc.solve(bd)
+    ginfo = pc.info()
+    xg.free()
+    dom_k = max(kernels, key=lambda k: k["share_of_step"]) if kernels else None
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_spmv_sell"}
+    if dom_k is not None:
+        roof = {"bound": "hbm", "achieved": dom_k["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom_k["hbm_GBs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom_k["kernel"],
+                "share_of_step": dom_k["share_of_step"], "avg_launch_ms": dom_k["avg_launch_ms"],
+                "launches_timed": dom_k["launches_timed"], "launches_total": dom_k["launches_total"],
+                "algorithmic_bytes_per_launch": dom_k["algorithmic_bytes_per_launch"]}
+    roof["kernels"] = kernels
+    roof["spmv_in_situ"] = {"GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                            "note": "working set %.0f MB > 256 MiB Infinity Cache: HBM-resident" % (by_sum.value / max(1, nsamp.value) / 1e6)}
+    out = {
+        "metric": "GenEO-PCG setup+solve sec and SpMV GB/s, 3D Laplacian 50M DoF, 1/2/4/8 GPUs",
+        "value": gbs, "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "ONE RANK'S SHARE of the metric's configuration, alone on one GPU: subdomain %d of the 2x2x2 "
+                               "decomposition of the %d^3 = %d DoF 7-pt Laplacian (reference tst/laplacian generator), overlap %d => "
+                               "%d local rows, -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g; set-up = every "
+                               "communication-free phase (SURVEY 8e), 'solve' = exactly %d PCG iterations on the local "
+                               "operator (local SpMV + M^-1 + dots each), no halo exchange, no all-reduce"
+                               % (args.rank_index, n, n ** 3, args.overlap, nloc, args.lvl, args.cut, args.tau, args.eps_tol,
+                                  args.apply_count),
+                   "grid": n, "dof": n ** 3, "subdomains": 8, "subdomains_per_gpu": 1, "rank_index": args.rank_index,
+                   "local_rows": nloc, "local_nnz": int(dom.a_neu.nnz), "overlap": args.overlap, "transport": "none (one rank of 8)"},
+        "setup_s": info["setupTime"], "solve_s": info["solveTime"], "setup_plus_solve_s": info["setupTime"] + info["solveTime"],
+        "first_setup_s": {"setup": cold[1], "solve": cold[2], "wall": cold[0],
+                          "note": "first set-up of the process: allocator empty, every block from hipMalloc"},
+        "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
+        "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
+        "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
+        "setup_breakdown_s": {"level1_upload_and_amg": info["lvl1SetupMinvTimeLoc"],
+                              "eigensolve_lobpcg": info["lvl2SetupEigTimeLoc"], "coarse_operator_E": info["lvl2SetupETimeLoc"]},
+        "untimed_step_with_hip_graphs_s": {"setup": ginfo["setupTime"], "solve": ginfo["solveTime"], "iterations": gits},
+        "solve_breakdown_s": {"local_solves": info["lvl1ApplyMinvTimeLoc"], "coarse_Zt": info["lvl2ApplyZtTimeLoc"],
+                              "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
+        "roofline": roof,
+    }
+    print(json.dumps(out), flush=True)
+    pc.destroy()
+
+
 def spawn(args):
     """N > 1 without torchrun: start the ranks as CHILD processes (this parent never touches the GPU) and relay."""
     s = socket.socket()
@@ -258,6 +371,8 @@ def spmv_hbm_resident(lib, doms):
 
 def main():
     args = build_parser().parse_args()
+    if args.one_rank_of:
+        return one_rank_of(args)
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(spawn(args))
 

@@ -80,6 +80,10 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
     const size_t c = value.find(',');
     if (c == std::string::npos || value.find(',', c + 1) != std::string::npos) return "invalid option -geneo_lvl";
     const std::string l1 = value.substr(0, c), l2 = value.substr(c + 1);
+    // a repeated -geneo_lvl replaces the earlier one (PETSc's options database keeps the last value of an option)
+    o.lvl1ASM = true;
+    o.lvl1RAS = o.lvl1SRAS = o.lvl1ORAS = false;
+    o.hybrid = o.effHybrid = false;
     if (l1 == "ASM") o.lvl1ASM = true;
     else if (l1 == "RAS") o.lvl1RAS = true;
     else if (l1 == "SRAS") o.lvl1RAS = o.lvl1SRAS = true;
@@ -198,11 +202,6 @@ struct PC::Amg1Pending {
 };
 
 static std::string check_id(int gid, int nsub);
-// Without -geneo_cut the reference keeps EVERY eigenvalue beyond the threshold (its nev is the LDLt inertia count,
-// geneo.cpp:502-560; the sweeps of tst/*/...Run.sh run that way).  The LOBPCG block holds 64 columns; subdomains of up
-// to DENSE_FALLBACK_ROWS rows whose count overflows it are handed to the dense path (whole spectrum on the host).
-static const int DENSE_FALLBACK_ROWS = 1500;
-static const int BLOCK_OVERFLOW = -51;
 
 int PC::fail(const std::string& msg) {
   last_error = msg;
@@ -1068,13 +1067,6 @@ int PC::setup_level2(const double* b_dev) {
   try {
     if (nmax <= 192) rc = eigen_dense_host();
     else rc = eigen_lobpcg();
-    if (rc == BLOCK_OVERFLOW) {
-      eigvals.assign(ns, {});
-      candidates.assign(ns, {});
-      info.estimDimELoc = info.nicolaidesLoc = 0;
-      if (int r1 = finish_amg1()) return r1;
-      rc = eigen_dense_host();
-    }
   } catch (std::exception& e) {
     return fail(e.what());
   }
@@ -1376,11 +1368,32 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   std::vector<std::vector<double>> res(ns, std::vector<double>(m, 1.0));
   lam.assign((size_t)ns * m, 0.0);
 
+  // Deflated restart: Q <- Q - Y_b (BY_b^T Q) for every locked block (Q: n_L x m inside a block of leading dimension ld).
+  // X and P are combinations of earlier [X P W], so projecting the start block and every W keeps the whole basis in the
+  // B-orthogonal complement of the locked vectors.
+  double* dGd = nullptr;
+  if (P.defl && !P.defl->empty()) {
+    int kmax_d = 0;
+    for (auto& b : *P.defl) kmax_d = std::max(kmax_d, b.k);
+    dGd = dv((size_t)ns * kmax_d * m);
+    owned_bufs.push_back(dGd);
+  }
+  auto deflate = [&](double* Q, int ld) {
+    if (!dGd) return;
+    for (auto& b : *P.defl) {
+      bk::gram(ch, b.BY, b.k, b.k, Q, ld, m, dGd);
+      bk::axpby(dGd, -1.0, dGd, 0.0, ns * b.k * m);
+      bk::block_mul(ch, b.Y, b.k, b.k, dGd, m, Q, ld, true);
+    }
+  };
   // ---- start block + Rayleigh-Ritz on X alone
-  bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed);
+  bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed + (uint64_t)P.seed_off);
+  deflate(S, p3);
   applyA(S, AS);
   applyB(S, BS);
   std::vector<char> frozen(ns, 0), locked((size_t)ns * m, 0);
+  if (P.skip)
+    for (int s = 0; s < ns; ++s) frozen[s] = P.skip[s] ? 1 : 0;
   std::vector<double> mask((size_t)ns * m, 1.0);
   double* dmask = dv((size_t)ns * m);
   owned_bufs.push_back(dmask);
@@ -1565,7 +1578,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   int it = 0;
   bool all_done = false;
   std::vector<int> nev_s(ns);
-  for (int s = 0; s < ns; ++s) nev_s[s] = std::min(nev_try, (int)subs[s].l2g.size());
+  for (int s = 0; s < ns; ++s)
+    nev_s[s] = std::max(0, std::min(nev_try, (int)subs[s].l2g.size() - (P.locked_cols ? P.locked_cols[s] : 0)));
   static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
   std::vector<double> lam_prev((size_t)ns * m, 1e300);   // Ritz values of the previous iteration (straggler test)
   // A pair is ACCEPTED at the tolerance but keeps iterating (its W / P columns stay in the basis) until it is far below
@@ -1635,7 +1649,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       for (int j = 0; j < m; ++j) nl += locked[(size_t)s * m + j] ? 1 : 0;
       fprintf(stderr, " %d", nl);
     }
-    fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[nev_s[0] - 1], P.amg ? "amg" : "cheb");
+    fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[std::max(1, nev_s[0]) - 1], P.amg ? "amg" : "cheb");
   };
   for (it = 0; it <= opt.eps_max_it; ++it) {
     // the A X / B X blocks are carried by recurrence (A S C); refresh them explicitly every few
@@ -1673,6 +1687,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
           rho = rho_new;
         }
       }
+      deflate(W, p3);
     };
     const bool reduced = have_prop && !full_gram && !(refresh > 0 && it % refresh == 0);
     // Two-stage pipeline of the host part (pipe): the subdomains are split into two groups; each group has its own Gram
@@ -1939,15 +1954,11 @@ int PC::eigen_lobpcg() {
   // B = D A_Dir D (geneo.cpp:1243-1247, MatDiagonalScale on a copy) as a values-only copy sharing A_Dir's index
   // arrays: the block products with B then run without the two scaling gathers per entry
   bk::Csr dirBD = bk::csr_scaled_alias(dirB, d_D, d_D, false);
-  double *Xt = nullptr, *Xg = nullptr;
   auto release = [&]() {
-    if (Xt) bk::dfree(Xt);
-    if (Xg) bk::dfree(Xg);
     bk::csr_free(dirBD);
     if (own_dirB) bk::csr_free(dirB);
   };
   info.eig_iterations = 0;
-  std::vector<double> lamT, muG;
   std::vector<HostCsr> robh;
   std::vector<const HostCsr*> hostB(ns);
   if (opt.check) {   // host copies of the pencils' right-hand matrices for checkSPD
@@ -1961,64 +1972,149 @@ int PC::eigen_lobpcg() {
       }
     }
   }
-  // Without -geneo_cut the reference keeps EVERY eigenvalue on the wanted side of the threshold (its nev is
-  // the LDLt inertia count, geneo.cpp:502-560).  There is no inertia count here: when the whole block lands
-  // on the wanted side, the block is doubled and the problem solved again (loud error beyond 64 columns).
-  auto solve_grow = [&](EigProblem P, bool gamma, int& mm, int& nev, std::vector<double>& lam, double*& X) -> int {
-    mm = m;
-    nev = nev_try;
-    for (;;) {
+  // Without -geneo_cut the reference keeps EVERY eigenvalue on the wanted side of the threshold (its nev is the LDLt
+  // inertia count, geneo.cpp:502-560, capped only by n and -geneo_cut; :713 keeps every lambda <= tau).  There is no
+  // inertia count here.  The block is doubled (16 -> 32 -> 64 columns) and the problem solved again while the whole
+  // block lands on the wanted side; once 48 pairs of a 64-column block are all wanted, they are LOCKED and the
+  // iteration restarts with a fresh block in the B-orthogonal complement of everything locked so far (deflated
+  // restart: lobpcg_solve projects the start block and every preconditioned residual), 48 more pairs per stage, until
+  // the threshold falls inside a block in every subdomain.  A subdomain whose threshold has been found sits out the
+  // later stages (frozen from the start).  The only ceiling left is the 256 coarse vectors per subdomain of the
+  // coarse-space kernels (ZMAXK), reported as an error.
+  struct Stage {
+    double* X = nullptr;            // n_L x m Ritz vectors of this stage
+    int m = 0;
+    std::vector<double> lam;        // ns x m
+    std::vector<int> count;         // per subdomain: leading columns that are candidates (0: it sat this stage out)
+  };
+  std::vector<double*> lock_bufs;   // Y / B Y copies of the locked blocks
+  auto free_stages = [&](std::vector<Stage>& st) {
+    for (auto& g : st)
+      if (g.X) bk::dfree(g.X);
+    st.clear();
+  };
+  auto solve_grow = [&](EigProblem P, bool gamma, std::vector<Stage>& out) -> int {
+    int mm = m, nev = nev_try;
+    auto wanted = [&](int s, double l) { return gamma ? (l > 0.0 && 1.0 / l >= gammaLoc[s]) : (l <= tauLoc[s]); };
+    Stage cur;
+    for (;;) {   // growth by re-solving with a wider block (cheap: these blocks are small)
       P.nev_try = nev;
-      X = dv((size_t)nL * mm);
-      if (int rc = lobpcg_solve(P, mm, lam, X)) return rc;
-      if (opt.cut > 0 || opt.noSyl || opt.eps_block > 0) return 0;
+      cur.X = dv((size_t)nL * mm);
+      cur.m = mm;
+      if (int rc = lobpcg_solve(P, mm, cur.lam, cur.X)) { bk::dfree(cur.X); return rc; }
+      cur.count.assign(ns, 0);
+      for (int s = 0; s < ns; ++s) cur.count[s] = std::min(nev, (int)subs[s].l2g.size());
+      if (opt.cut > 0 || opt.noSyl || opt.eps_block > 0) { out.push_back(cur); return 0; }
       bool full = false;
       for (int s = 0; s < ns; ++s) {
-        const int n_s = (int)subs[s].l2g.size(), nv = std::min(nev, n_s);
+        const int n_s = (int)subs[s].l2g.size(), nv = cur.count[s];
         if (nv >= n_s) continue;
-        const double last = lam[(size_t)s * mm + nv - 1];
-        if (last >= 1e299) continue;
-        if (gamma ? (last > 0.0 && 1.0 / last >= gammaLoc[s]) : (last <= tauLoc[s])) full = true;
+        const double last = cur.lam[(size_t)s * mm + nv - 1];
+        if (last < 1e299 && wanted(s, last)) full = true;
       }
-      if (!full) return 0;
-      if (nev >= 51) {
-        int nmax = 0;
-        for (auto& sd : subs) nmax = std::max(nmax, (int)sd.l2g.size());
-        if (nmax <= DENSE_FALLBACK_ROWS) return BLOCK_OVERFLOW;   // small subdomains: the caller takes the dense path
-        return fail("GenEO: more than 51 eigenvalues pass the threshold in one subdomain and the LOBPCG block holds 64 "
-                    "columns: set -geneo_cut (or lower -geneo_tau)");
-      }
-      bk::dfree(X);
-      X = nullptr;
-      nev = std::min(51, 2 * nev);
+      if (!full) { out.push_back(cur); return 0; }
+      if (nev >= 48) break;
+      bk::dfree(cur.X);
+      cur.X = nullptr;
+      nev = std::min(48, 2 * nev);
       const int want = nev + std::max(4, nev / 4);
       mm = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
     }
+    // ---- deflated restarts: 64-column blocks, 48 pairs asked per stage
+    std::vector<EigProblem::Locked> locked_blocks;
+    std::vector<int> locked_cols(ns, 0);
+    std::vector<char> skip(ns, 0);
+    for (int stage = 1;; ++stage) {
+      // lock the candidates of the subdomains that are still full; the others are done
+      std::vector<double> cs((size_t)ns * cur.m, 0.0);
+      bool any = false;
+      for (int s = 0; s < ns; ++s) {
+        const int n_s = (int)subs[s].l2g.size(), nv = cur.count[s];
+        bool full = !skip[s] && nv > 0 && locked_cols[s] + nv < n_s;
+        if (full) {
+          const double last = cur.lam[(size_t)s * cur.m + nv - 1];
+          full = last < 1e299 && wanted(s, last);
+        }
+        if (!full) { skip[s] = 1; continue; }
+        any = true;
+        for (int j = 0; j < nv; ++j) cs[(size_t)s * cur.m + j] = 1.0;
+        locked_cols[s] += nv;
+        if (locked_cols[s] + 48 > 256)
+          return fail("GenEO: more than 256 eigenvalues pass the threshold in one subdomain (coarse-space kernels hold 256 "
+                      "vectors per subdomain): set -geneo_cut or lower -geneo_tau");
+      }
+      out.push_back(cur);
+      if (!any) return 0;
+      double* Y = dv((size_t)nL * cur.m);
+      double* BY = dv((size_t)nL * cur.m);
+      lock_bufs.push_back(Y);
+      lock_bufs.push_back(BY);
+      double* dcs = dv(cs.size());
+      bk::h2d(dcs, cs.data(), sizeof(double) * cs.size());
+      bk::block_axpby(Y, cur.m, 1.0, cur.X, cur.m, 0.0, nL, cur.m);
+      bk::block_colscale(ch, Y, cur.m, cur.m, dcs);
+      bk::spmm_strided(*P.B, Y, cur.m, BY, cur.m, cur.m, P.Bs, P.Bs);
+      bk::sync();
+      bk::dfree(dcs);
+      locked_blocks.push_back({Y, BY, cur.m});
+      Stage nxt;
+      nxt.m = 64;
+      nxt.X = dv((size_t)nL * 64);
+      EigProblem Pd = P;
+      Pd.nev_try = 48;
+      Pd.defl = &locked_blocks;
+      Pd.skip = skip.data();
+      Pd.locked_cols = locked_cols.data();
+      Pd.seed_off = stage;
+      if (int rc = lobpcg_solve(Pd, 64, nxt.lam, nxt.X)) { bk::dfree(nxt.X); return rc; }
+      nxt.count.assign(ns, 0);
+      for (int s = 0; s < ns; ++s)
+        if (!skip[s]) nxt.count[s] = std::max(0, std::min(48, (int)subs[s].l2g.size() - locked_cols[s]));
+      cur = nxt;
+    }
   };
-  int m_t = m, m_g = m, nev_t = nev_try, nev_g = nev_try;
+  std::vector<Stage> stT, stG;
+  auto release_all = [&]() {
+    free_stages(stT);
+    free_stages(stG);
+    for (double* q : lock_bufs) bk::dfree(q);
+    lock_bufs.clear();
+    release();
+  };
   {
     EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirBD, nullptr, (opt.els2_pc == "amg") ? amgN : nullptr,
                   d_dinvN, cheb_lmax, nev_try, "tau"};
     if (opt.check)
-      if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release(); return rc; }
-    if (int rc = solve_grow(pt, false, m_t, nev_t, lamT, Xt)) { release(); return rc; }
+      if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release_all(); return rc; }
+    if (int rc = solve_grow(pt, false, stT)) { release_all(); return rc; }
   }
   if (g2) {
-    if (int rc = local_gamma()) { release(); return rc; }
-    if (int rc = finish_amg1()) { release(); return rc; }   // the gamma problem runs through the level-1 hierarchy
+    if (int rc = local_gamma()) { release_all(); return rc; }
+    if (int rc = finish_amg1()) { release_all(); return rc; }   // the gamma problem runs through the level-1 hierarchy
     EigProblem pg{&dirL, nullptr, &dirBD, nullptr, (opt.els2_pc == "amg" && opt.dls1_pc == "amg") ? amg1 : nullptr,
                   d_dinv1, cheb_lmax1, nev_try, "gamma"};
     if (opt.check) {  // the reference checks the B of the gamma pencil as given to SLEPc: A_Rob (geneo.cpp:1299,:884)
       EigProblem pchk = pg;
       pchk.B = &dirL;
       pchk.Bs = nullptr;
-      if (int rc = check_local_spd(pchk, hostB.data(), false)) { release(); return rc; }
+      if (int rc = check_local_spd(pchk, hostB.data(), false)) { release_all(); return rc; }
     }
-    if (int rc = solve_grow(pg, true, m_g, nev_g, muG, Xg)) { release(); return rc; }
+    if (int rc = solve_grow(pg, true, stG)) { release_all(); return rc; }
   }
+  for (double* q : lock_bufs) bk::dfree(q);     // the locked copies are no longer needed (the stages keep their own X)
+  lock_bufs.clear();
   // ---- selection (geneo.cpp:709-722), Nicolaides (:897-944), empty-Z rule (:1305-1314)
-  std::vector<int> selT((size_t)ns * m_t, 0), selG((size_t)ns * m_g, 0), kT(ns, 0), kG(ns, 0);
-  std::vector<double> gscale((size_t)ns * m_g, 1.0);
+  // sel[stage][s * m + j]: column of that stage's X that becomes the j-th vector the stage contributes to Z_s (-1: the
+  // constant vector, carried by the first tau stage)
+  auto make_sel = [&](const std::vector<Stage>& st) {
+    std::vector<std::vector<int>> v(st.size());
+    for (size_t g = 0; g < st.size(); ++g) v[g].assign((size_t)ns * (st[g].m + 1), 0);
+    return v;
+  };
+  std::vector<std::vector<int>> selT = make_sel(stT), selG = make_sel(stG);
+  std::vector<std::vector<int>> kT(stT.size(), std::vector<int>(ns, 0)), kG(stG.size(), std::vector<int>(ns, 0));
+  std::vector<std::vector<double>> gscale(stG.size());
+  for (size_t g = 0; g < stG.size(); ++g) gscale[g].assign((size_t)ns * stG[g].m, 1.0);
   ksub.assign(ns, 0);
   double* ones = d_cg_p;
   double* tmp = d_cg_q;
@@ -2036,80 +2132,95 @@ int PC::eigen_lobpcg() {
   std::vector<double> sc((size_t)8 * ns);
   bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
   for (int s = 0; s < ns; ++s) {
-    const int nevT = std::min(nev_t, (int)subs[s].l2g.size()), nevG = std::min(nev_g, (int)subs[s].l2g.size());
     int cnt = 0;
     double minval = 1e300;
-    for (int j = 0; j < nevT; ++j) {
-      const double l = lamT[(size_t)s * m_t + j];
-      if (l >= 1e299) continue;
-      candidates[s].push_back(l);
-      if (l > tauLoc[s]) continue;
-      selT[(size_t)s * m_t + cnt++] = j;
-      eigvals[s].push_back(l);
-      minval = std::min(minval, l);
+    for (size_t g = 0; g < stT.size(); ++g) {
+      const Stage& st = stT[g];
+      const int stride = st.m + 1;
+      for (int j = 0; j < st.count[s]; ++j) {
+        const double l = st.lam[(size_t)s * st.m + j];
+        if (l >= 1e299) continue;
+        candidates[s].push_back(l);
+        if (l > tauLoc[s]) continue;
+        selT[g][(size_t)s * stride + kT[g][s]++] = j;
+        ++cnt;
+        eigvals[s].push_back(l);
+        minval = std::min(minval, l);
+      }
     }
     if (cnt > 0 && minval >= DBL_EPSILON) {
       const double ratio = std::fabs(sc[(size_t)s * 8 + 0] / sc[(size_t)s * 8 + 1]);
       if (ratio <= FLT_EPSILON) {
-        selT[(size_t)s * m_t + cnt++] = -1;
+        const size_t g = stT.size() - 1;      // appended behind every eigenvector, as the reference does (:897-944)
+        selT[g][(size_t)s * (stT[g].m + 1) + kT[g][s]++] = -1;
+        ++cnt;
         eigvals[s].push_back(0.0);
         info.nicolaidesLoc++;
       }
     }
-    kT[s] = cnt;
     int cg = 0;
-    if (g2) {
-      for (int j = 0; j < nevG; ++j) {
-        const double mu = muG[(size_t)s * m_g + j];
+    for (size_t g = 0; g < stG.size(); ++g) {
+      const Stage& st = stG[g];
+      const int stride = st.m + 1;
+      for (int j = 0; j < st.count[s]; ++j) {
+        const double mu = st.lam[(size_t)s * st.m + j];
         if (mu >= 1e299 || !(mu > 0.0)) continue;
         const double l = 1.0 / mu;
         candidates[s].push_back(l);
         if (l < gammaLoc[s]) continue;
-        gscale[(size_t)s * m_g + j] = std::sqrt(l);  // SLEPc normalisation v^T A_Rob v = 1 (ours: v^T B_w v = 1)
-        selG[(size_t)s * m_g + cg++] = j;
+        gscale[g][(size_t)s * st.m + j] = std::sqrt(l);  // SLEPc normalisation v^T A_Rob v = 1 (ours: v^T B_w v = 1)
+        selG[g][(size_t)s * stride + kG[g][s]++] = j;
+        ++cg;
         eigvals[s].push_back(l);
       }
     }
     if (cnt + cg == 0) {
-      selT[(size_t)s * m_t + cnt++] = -1;
+      selT[0][(size_t)s * (stT[0].m + 1) + kT[0][s]++] = -1;
+      ++cnt;
       eigvals[s].push_back(0.0);
       info.nicolaidesLoc++;
-      kT[s] = cnt;
     }
-    kG[s] = cg;
     info.estimDimELoc += cnt + cg;
     ksub[s] = cnt + cg;
+    if (ksub[s] > 256) {
+      release_all();
+      return fail("GenEO: more than 256 coarse vectors in one subdomain: set -geneo_cut or lower -geneo_tau");
+    }
   }
-  std::vector<int64_t> zbase(ns + 1, 0), zbaseG(ns + 1, 0);
-  for (int s = 0; s < ns; ++s) {
-    zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
-    zbaseG[s] = zbase[s] + (int64_t)kT[s] * (int64_t)subs[s].l2g.size();
-  }
+  std::vector<int64_t> zbase(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
   d_Z = (double*)bk::alloc(sizeof(double) * (size_t)std::max<int64_t>(1, zbase[ns]));
   d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
-  int64_t* dzb = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
-  int* dsel = (int*)bk::alloc(sizeof(int) * std::max(selT.size(), selG.size()));
-  int* dks = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
   bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
-  bk::h2d(dsel, selT.data(), sizeof(int) * selT.size());
-  bk::h2d(dks, kT.data(), sizeof(int) * ns);
-  bk::block_extract(ch, Xt, m_t, m_t, d_D, dsel, dks, d_zbase, d_Z);
-  bk::sync();
-  if (g2) {
-    double* dgs = dv(gscale.size());
-    bk::h2d(dgs, gscale.data(), sizeof(double) * gscale.size());
-    bk::block_colscale(ch, Xg, m_g, m_g, dgs);
-    bk::h2d(dzb, zbaseG.data(), sizeof(int64_t) * (ns + 1));
-    bk::h2d(dsel, selG.data(), sizeof(int) * selG.size());
-    bk::h2d(dks, kG.data(), sizeof(int) * ns);
-    bk::block_extract(ch, Xg, m_g, m_g, d_D, dsel, dks, dzb, d_Z);
+  int64_t* dzb = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
+  size_t selmax = 1;
+  for (auto& v : selT) selmax = std::max(selmax, v.size());
+  for (auto& v : selG) selmax = std::max(selmax, v.size());
+  int* dsel = (int*)bk::alloc(sizeof(int) * selmax);
+  int* dks = (int*)bk::alloc(sizeof(int) * std::max(1, ns));
+  // every stage writes its vectors behind those of the stages before it
+  std::vector<int64_t> zcur(zbase.begin(), zbase.end());
+  auto extract = [&](Stage& st, const std::vector<int>& sel, const std::vector<int>& ks, const double* colscale) {
+    if (colscale) {
+      double* dgs = dv((size_t)ns * st.m);
+      bk::h2d(dgs, colscale, sizeof(double) * (size_t)ns * st.m);
+      bk::block_colscale(ch, st.X, st.m, st.m, dgs);
+      bk::sync();
+      bk::dfree(dgs);
+    }
+    bk::h2d(dzb, zcur.data(), sizeof(int64_t) * (ns + 1));
+    bk::h2d(dsel, sel.data(), sizeof(int) * sel.size());
+    bk::h2d(dks, ks.data(), sizeof(int) * ns);
+    bk::block_extract(ch, st.X, st.m, st.m + 1, d_D, dsel, dks, dzb, d_Z);
     bk::sync();
-    bk::dfree(dgs);
-  }
+    for (int s = 0; s < ns; ++s) zcur[s] += (int64_t)ks[s] * (int64_t)subs[s].l2g.size();
+  };
+  for (size_t g = 0; g < stT.size(); ++g) extract(stT[g], selT[g], kT[g], nullptr);
+  for (size_t g = 0; g < stG.size(); ++g) extract(stG[g], selG[g], kG[g], gscale[g].data());
   bk::dfree(dzb);
   bk::dfree(dsel);
   bk::dfree(dks);
-  release();
+  release_all();
   return 0;
 }
 

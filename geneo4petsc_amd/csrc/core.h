@@ -183,6 +183,14 @@ class PC {
     const double* dinv; double lmax;      // Jacobi scaling and Gershgorin bound for the Chebyshev fallback
     int nev_try;
     const char* label;
+    // deflated restart (no -geneo_cut and more eigenvalues below the threshold than one block holds): the iteration runs
+    // in the B-orthogonal complement of the locked blocks Y_b (n_L x k_b row-major, B-orthonormal per subdomain, zero
+    // columns where a subdomain locked fewer), BY_b = B Y_b; subdomains with skip[s] != 0 are frozen from the start
+    struct Locked { const double* Y; const double* BY; int k; };
+    const std::vector<Locked>* defl = nullptr;
+    const char* skip = nullptr;
+    const int* locked_cols = nullptr;     // per subdomain: columns locked so far (bounds the pairs that can still be asked for)
+    int seed_off = 0;
   };
   int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
   int eig_targets(int* nev_try) const;

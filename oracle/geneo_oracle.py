@@ -95,6 +95,8 @@ def parse_options(args: List[str]) -> GenEOOptions:
             if len(parts) != 2:
                 raise ValueError("invalid option -geneo_lvl")
             l1, l2 = parts
+            # a repeated -geneo_lvl replaces the earlier one (PETSc's options database keeps the last value)
+            o.lvl1ASM, o.lvl1RAS, o.lvl1SRAS, o.lvl1ORAS = True, False, False, False
             if l1 == "ASM":
                 o.lvl1ASM = True
             elif l1 == "RAS":

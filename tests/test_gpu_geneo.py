@@ -180,15 +180,18 @@ def test_vcycle_storage_and_form_do_not_change_the_result(lib, precision, post, 
     whose subdomains are large enough for a three-level hierarchy (20^3 in 8 subdomains, AMG inner solves)."""
     if post:
         monkeypatch.setenv("GENEO_AMG_NO_POST_MATRIX", post)
-    # no -geneo_cut: the threshold keeps whole multiplets (a cut inside one leaves the choice of its members, and with
-    # it the iteration count, to the eigensolver)
-    # and GMRES to 1e-6 (23 iterations): beyond ~16 iterations at this size the residual histories of two correct
-    # implementations drift apart by tens of per cent (1e-9 differences of the local solves, amplified), so a count
-    # taken at 1e-8 (32 against 31) measures that noise, not the preconditioner
-    argv = ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.2", "-ksp_type", "gmres", "-dls1_pc_type", "amg",
-            "-els2_pc_type", "amg", "-dls1_amg_precision", precision, "-amg_coarse_size", "100",
-            "-ksp_gmres_restart", "100"] + TIGHT + ["-ksp_rtol", "1e-6"]
-    _, info = cases.compare_with_oracle(lib, 20, (2, 2, 2), 2, argv, xtol=1e-6)    # two iterates at a Krylov tolerance of 1e-6
+    # Round 2 saw GMRES(30) stop after 33 iterations here where the oracle needs 32 (gpurun_out/s2.log) and answered by
+    # loosening the test.  The cause, isolated in round 3 on the same argv (tests/test_oracle_eig.py::
+    # test_gmres_count_at_1e8_moves_with_a_1e10_perturbation_of_the_oracle_itself): NOT the inexact local solves
+    # (-dls1_ksp_rtol 1e-14 and -dls1_pc_type jacobi give the same 33) and NOT a cut inside a multiplet (cut 12 takes the
+    # whole doublet 0.204296.. of the corner subdomains; the near-triplet 0.20584377 / ..77 / ..82 of the others is split
+    # 5e-8 apart), but the eigenvectors: converged to 1e-10 they perturb Z E^-1 Z^T by 1e-10, and the ORACLE ITSELF, with
+    # its preconditioner perturbed by a fixed relative 1e-10 (1e-12), needs 33 (34) iterations instead of 32 at rtol 1e-8
+    # -- by iteration 18 two Krylov processes whose operators differ by 1e-10 are no longer the same sequence.  With the
+    # eigenvectors at 1e-12 the library reproduces the oracle's 32; the original parameters are restored with that.
+    argv = ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.35", "-geneo_cut", "12", "-ksp_type", "gmres", "-dls1_pc_type", "amg",
+            "-els2_pc_type", "amg", "-dls1_amg_precision", precision, "-amg_coarse_size", "100"] + TIGHT + ["-els2_eps_tol", "1e-12"]
+    _, info = cases.compare_with_oracle(lib, 20, (2, 2, 2), 2, argv)
     assert info["amg_levels"] >= 3
 
 
@@ -226,3 +229,16 @@ def test_reference_style_entry_points(lib, style):
     q = one * (one @ b) / (one @ (a @ one))
     np.testing.assert_allclose(pc.apply(b), np.arange(1.0, n + 1.0) + q, rtol=1e-7)
     pc.destroy()
+
+
+@pytest.mark.parametrize("lvl,tau,dim_e", [("ASM,1", "0.6", 1256), ("SRAS,1", "0.5", None)])
+def test_no_cut_deflated_restarts(lib, lvl, tau, dim_e):
+    """Row a7: every eigenvalue below tau enters Z, for any count (geneo.cpp:502-560, :713) -- 16^3 in 8 subdomains of
+    729 rows, no -geneo_cut: 157 vectors per subdomain at tau 0.6 (four deflated restarts behind the 64-column block),
+    on LOBPCG-sized subdomains (the dense host path stops at 192 rows).  dimE, kept counts, eigenvalues to 1e-10 and the
+    GMRES count equal the oracle's."""
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", tau, "-ksp_type", "gmres"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 16, (2, 2, 2), 1, argv)
+    assert info["dimE"] >= 8 * 70
+    if dim_e:
+        assert info["dimE"] == dim_e

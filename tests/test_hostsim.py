@@ -261,3 +261,13 @@ def test_reference_style_entry_points_one_subdomain_per_rank(lib, style):
     y = pc.apply(b)
     np.testing.assert_allclose(y, np.arange(1.0, n + 1.0), rtol=1e-8)
     pc.destroy()
+
+
+def test_no_cut_more_eigenvalues_below_tau_than_one_block_holds(lib):
+    """Row a7 (geneo.cpp:502-560, :713): without -geneo_cut the reference keeps EVERY eigenvalue below tau, whatever their
+    number.  12^3 in 8 subdomains of 343 rows (> 192: the LOBPCG path, not the dense one), tau 0.6: 79 vectors per
+    subdomain -- block growth 16 -> 32 -> 64, then deflated restarts (48 locked pairs per stage, the next block iterated
+    in the B-orthogonal complement).  dimE, kept counts, eigenvalues (1e-10) and the GMRES count equal the oracle's."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.6", "-ksp_type", "gmres"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv)
+    assert info["dimE"] == 632 and info["realDimELoc"] == 632
