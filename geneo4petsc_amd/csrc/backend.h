@@ -19,7 +19,13 @@ namespace bk {
 const char* name();                       // "hip-gfx950" | "hostsim"
 void set_stream(void* hip_stream);        // stream used for every launch / async copy
 void* get_stream();
-void sync();                              // wait for the stream
+void sync();                              // wait for the calling thread's stream
+// A host thread may move ITS launches, copies and allocations to a private stream: begin orders that stream behind
+// everything queued on the main stream so far, end waits for it (results are then safe on any stream) and returns the
+// thread to the main stream.  Cached device blocks carry the stream of their last user, so blocks travel safely
+// between the two.  The level-1 hierarchy is built this way while the main stream runs the eigensolve.
+void side_stream_begin();
+void side_stream_end();
 
 void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
 void  dfree(void* p);

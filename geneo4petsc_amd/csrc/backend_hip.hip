@@ -38,8 +38,17 @@
 
 namespace bk {
 
-static hipStream_t g_stream = nullptr;
-static bool g_capturing = false;   // between graph_capture_begin and graph_capture_end
+// The library stream.  One MAIN stream (set by the host: GeneoSetStream) carries the solver; a host thread may switch
+// ITS launches, copies and allocations to a private side stream (side_stream_begin / side_stream_end): the level-1
+// hierarchy is built that way while the main stream runs the eigensolve.  Every `g_stream` below is the calling
+// thread's current stream.
+static hipStream_t g_stream_main = nullptr;
+static thread_local hipStream_t t_stream_side = nullptr;
+static thread_local bool t_side = false;
+static thread_local bool g_capturing = false;   // between graph_capture_begin and graph_capture_end (per thread)
+static thread_local hipStream_t g_capture_stream = nullptr;   // launches of a capturing thread are recorded here
+static inline hipStream_t stream_cur() { return g_capturing ? g_capture_stream : (t_side ? t_stream_side : g_stream_main); }
+#define g_stream (stream_cur())
 static bool g_no_mfma = false;
 static bool g_init = false;
 
@@ -51,7 +60,30 @@ static void lazy_init() {
 }
 
 const char* name() { return "hip-gfx950"; }
-void set_stream(void* s) { g_stream = (hipStream_t)s; }
+void set_stream(void* s) {
+  // a new main stream: everything queued on the old one is finished first (cached blocks and scratch buffers carry no
+  // ordering between two main streams otherwise)
+  if ((hipStream_t)s != g_stream_main) (void)hipStreamSynchronize(g_stream_main);
+  g_stream_main = (hipStream_t)s;
+}
+void side_stream_begin() {
+  if (t_side) return;
+  if (!t_stream_side) HIPCHK(hipStreamCreateWithFlags(&t_stream_side, hipStreamNonBlocking));
+  // ordered behind everything the main stream has been given so far (the matrices this thread is going to read)
+  hipEvent_t ev;
+  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ev, g_stream_main));
+  HIPCHK(hipStreamWaitEvent(t_stream_side, ev, 0));
+  (void)hipEventDestroy(ev);
+  t_side = true;
+}
+void side_stream_end() {
+  if (!t_side) return;
+  (void)hipStreamSynchronize(t_stream_side);     // whoever joins this thread may use its results on any stream
+  t_side = false;
+  (void)hipStreamDestroy(t_stream_side);
+  t_stream_side = nullptr;
+}
 void* get_stream() { return (void*)g_stream; }
 void sync() { HIPCHK(hipStreamSynchronize(g_stream)); }
 
@@ -66,14 +98,18 @@ static long long g_alloc_n = 0;
 // GENEO_ALLOC_CACHE_GB (default 96); GENEO_ALLOC_CACHE=0 turns it off.
 static std::mutex g_alloc_mu;
 static std::unordered_map<void*, size_t> g_live;
-static std::multimap<size_t, void*> g_cache;
+// a parked block remembers the stream its last user ran on and an event recorded there when it was freed: the next
+// owner on the SAME stream needs no synchronisation (stream order), one on another stream waits for the event
+struct Parked { void* p; hipStream_t stream; hipEvent_t ev; };
+static std::multimap<size_t, Parked> g_cache;
+static std::vector<hipEvent_t> g_ev_pool;
 static size_t g_cache_bytes = 0;
 static bool alloc_cache_on() {
   static const bool on = !(getenv("GENEO_ALLOC_CACHE") && !strcmp(getenv("GENEO_ALLOC_CACHE"), "0"));
   return on;
 }
 static size_t alloc_cache_cap() {
-  static const size_t cap = (size_t)(getenv("GENEO_ALLOC_CACHE_GB") ? atof(getenv("GENEO_ALLOC_CACHE_GB")) : 96.0) << 30;
+  static const size_t cap = (size_t)((getenv("GENEO_ALLOC_CACHE_GB") ? atof(getenv("GENEO_ALLOC_CACHE_GB")) : 96.0) * 1073741824.0);
   return cap;
 }
 static inline size_t alloc_round(size_t bytes) {
@@ -84,8 +120,11 @@ void alloc_cache_release() {
   std::lock_guard<std::mutex> lk(g_alloc_mu);
   if (g_cache.empty()) return;
   auto t0 = std::chrono::high_resolution_clock::now();
-  (void)hipStreamSynchronize(g_stream);
-  for (auto& kv : g_cache) (void)hipFree(kv.second);
+  (void)hipDeviceSynchronize();                  // parked blocks may have been used on any stream
+  for (auto& kv : g_cache) {
+    (void)hipFree(kv.second.p);
+    if (kv.second.ev) g_ev_pool.push_back(kv.second.ev);
+  }
   g_cache.clear();
   g_cache_bytes = 0;
   g_free_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -99,7 +138,11 @@ void* alloc(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     auto it = g_cache.lower_bound(sz);
     if (it != g_cache.end() && it->first <= sz + sz / 8 + 4096) {
-      p = it->second;
+      p = it->second.p;
+      if (it->second.ev) {
+        if (it->second.stream != g_stream) (void)hipStreamWaitEvent(g_stream, it->second.ev, 0);
+        g_ev_pool.push_back(it->second.ev);
+      }
       g_live[p] = it->first;
       g_cache_bytes -= it->first;
       g_cache.erase(it);
@@ -134,7 +177,13 @@ void dfree(void* p) {
       const size_t sz = it->second;
       g_live.erase(it);
       if (g_cache_bytes + sz <= alloc_cache_cap()) {
-        g_cache.emplace(sz, p);
+        Parked pk{p, g_stream, nullptr};
+        if (!g_capturing) {
+          if (!g_ev_pool.empty()) { pk.ev = g_ev_pool.back(); g_ev_pool.pop_back(); }
+          else if (hipEventCreateWithFlags(&pk.ev, hipEventDisableTiming) != hipSuccess) pk.ev = nullptr;
+          if (pk.ev && hipEventRecord(pk.ev, g_stream) != hipSuccess) { g_ev_pool.push_back(pk.ev); pk.ev = nullptr; }
+        }
+        g_cache.emplace(sz, pk);
         g_cache_bytes += sz;
         return;
       }
@@ -168,9 +217,12 @@ static bool stage_ready() {
   }
   return true;
 }
+static std::mutex g_stage_mu;    // the two pinned buffers are shared by the threads that copy (main + side stream)
 void h2d(void* d, const void* h, size_t bytes) {
   if (!bytes) return;
-  if (bytes >= 2 * STAGE_BYTES && !g_capturing && stage_ready()) {
+  if (bytes >= 2 * STAGE_BYTES && !g_capturing) {
+   std::lock_guard<std::mutex> lk(g_stage_mu);
+   if (stage_ready()) {
     size_t off = 0;
     for (int i = 0; off < bytes; ++i, off += STAGE_BYTES) {
       const int b = i & 1;
@@ -182,13 +234,16 @@ void h2d(void* d, const void* h, size_t bytes) {
     }
     HIPCHK(hipStreamSynchronize(g_stream));
     return;
+   }
   }
   HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));  // h may be pageable / reused by the caller
 }
 void d2h(void* h, const void* d, size_t bytes) {
   if (!bytes) return;
-  if (bytes >= 2 * STAGE_BYTES && !g_capturing && stage_ready()) {
+  if (bytes >= 2 * STAGE_BYTES && !g_capturing) {
+   std::lock_guard<std::mutex> lk(g_stage_mu);
+   if (stage_ready()) {
     const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto issue = [&](size_t i) {
       const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
@@ -203,6 +258,7 @@ void d2h(void* h, const void* d, size_t bytes) {
       std::memcpy((char*)h + off, g_stage[i & 1], len);
     }
     return;
+   }
   }
   HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
@@ -222,7 +278,6 @@ static void graph_counts_reset();
 static void graph_counts_store(void* exec);
 static void graph_counts_add(void* exec);
 static void graph_counts_drop(void* exec);
-static hipStream_t g_capture_stream = nullptr, g_saved_stream = nullptr;
 bool graph_capture_begin() {
   if (g_capturing || getenv("GENEO_NO_GRAPH")) return false;
   if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -231,8 +286,6 @@ bool graph_capture_begin() {
   }
   HIPCHK(hipStreamSynchronize(g_stream));
   if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
-  g_saved_stream = g_stream;
-  g_stream = g_capture_stream;
   g_capturing = true;
   graph_counts_reset();
   return true;
@@ -241,7 +294,6 @@ void* graph_capture_end() {
   if (!g_capturing) return nullptr;
   hipGraph_t graph = nullptr;
   const hipError_t e = hipStreamEndCapture(g_capture_stream, &graph);
-  g_stream = g_saved_stream;
   g_capturing = false;
   if (e != hipSuccess || !graph) return nullptr;
   hipGraphExec_t exec = nullptr;

@@ -14,6 +14,7 @@
 // broadcasts the bytes by whatever channel it has: MPI_Bcast, torch.distributed, a file).
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,8 +48,17 @@ bool load_api() {
   if (g_api.handle) return true;
   void* h = nullptr;
   const char* names[] = {"librccl.so.1", "librccl.so"};
+  // GENEO_RCCL_LIBRARY: full path of the library to bind instead (a site build of RCCL; the two-process CPU test of this
+  // transport binds a shared-memory stand-in this way, tests/test_rccl_two_peers.py)
+  const char* over = getenv("GENEO_RCCL_LIBRARY");
+  if (over && *over) {
+    if (!(h = dlopen(over, RTLD_NOW | RTLD_LOCAL))) {
+      g_err = std::string("GenEO: cannot load GENEO_RCCL_LIBRARY ") + over + ": " + (dlerror() ? dlerror() : "not found");
+      return false;
+    }
+  }
   for (const char* n : names)            // the instance the process already has (same soname), if any
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+    if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
   if (!h)
     for (const char* n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;

@@ -195,9 +195,12 @@ struct AmgHostResult {
 struct PC::Amg1Pending {
   HostCsr mat;
   AmgHostResult res;
+  AmgDevice* dev = nullptr;     // uploaded by the same thread on its side stream (handed to PC::amg1 at the join)
+  double upload_secs = 0.0;
   std::thread th;
   ~Amg1Pending() {
     if (th.joinable()) th.join();
+    delete dev;
   }
 };
 
@@ -549,27 +552,17 @@ int PC::finish_amg1() {
   const double waited = secs(t0, clk::now());
   std::unique_ptr<Amg1Pending> p(pend1.release());
   if (!p->res.err.empty()) return fail(p->res.err);
-  try {
-    amg1 = new AmgDevice();
-    // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
-    AmgParams ap1 = amg_params(opt);
-    ap1.single = opt.dls1_amg_single;
-    ap1.strength = opt.dls1_amg_strength;
-    amg1->upload(p->res.levels, p->res.cinv, p->res.cbase, ap1,
-                 (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1, &dirL);
-    info.amg_levels = amg1->nlevels();
-    info.amg_operator_complexity = amg1->operator_complexity();
-    if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] level-1 hierarchy: %d matrices with a single-precision companion\n", amg1->lp_matrices());
-  } catch (std::exception& e) {
-    return fail(e.what());
-  }
-  bk::sync();
+  amg1 = p->dev;             // built and uploaded by the thread, on its side stream, while this one ran the eigensolve
+  p->dev = nullptr;
+  info.amg_levels = amg1->nlevels();
+  info.amg_operator_complexity = amg1->operator_complexity();
+  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] level-1 hierarchy: %d matrices with a single-precision companion\n", amg1->lp_matrices());
   const double tot = secs(t0, clk::now());
   info.amgSetupTime += tot;
   info.lvl1SetupMinvTimeLoc += tot;
   if (getenv("GENEO_DEBUG"))
-    fprintf(stderr, "[amg] level-1 host set-up %.3f s on its own thread, waited %.3f s for it, upload %.3f s\n", p->res.secs, waited,
-            tot - waited);
+    fprintf(stderr, "[amg] level-1 hierarchy on its own thread: host set-up %.3f s, upload on the side stream %.3f s; waited %.3f s for it\n",
+            p->res.secs, p->upload_secs, waited);
   return 0;
 }
 
@@ -586,6 +579,7 @@ int PC::setup(const double* b_dev) {
     return fail("GenEO-2 needs the Robin matrix: use -geneo_lvl ORAS,2 or SORAS,2 (geneo.cpp:1283 takes pcARobLoc)");
   if (N <= 0) return fail("GenEO preconditioner: empty problem");
   if (int rc = build_layout()) return rc;
+  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] %-28s %.3f s\n", "layout (maps, R^T, work vectors)", secs(t0, clk::now()));
   if (int rc = ensure_dirichlet()) return rc;
   const int ns = (int)subs.size();
   for (auto& s : subs) {
@@ -707,18 +701,35 @@ int PC::setup(const double* b_dev) {
     ap1h.strength = opt.dls1_amg_strength;
     AmgParams apN = ap;                       // the A_Neu hierarchy (LOBPCG preconditioner)
     apN.strength = opt.els2_amg_strength;
-    auto start1 = [this, ap1h]() {
+    // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
+    const int max_m1 = (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1;
+    auto start1 = [this, ap1h, max_m1]() {
       Amg1Pending* pp = pend1.get();
       const std::vector<int> so = suboff;
-      const AmgParams ap = ap1h;
-      pp->th = std::thread([pp, so, ap]() {
+      AmgParams ap = ap1h;
+      ap.single = opt.dls1_amg_single;
+      const bk::Csr* fine = &dirL;          // uploaded (with its companion) before this thread starts; outlives it
+      pp->th = std::thread([pp, so, ap, max_m1, fine]() {
         auto t0 = clk::now();
         try {
           amg_setup_host(pp->mat, so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
+          pp->res.secs = secs(t0, clk::now());
+          // upload + device-side products (R = P^T, M = P - w D^-1 A P, companions) on a private stream, concurrently
+          // with whatever the main stream is running (the eigensolve)
+          auto t1 = clk::now();
+          bk::side_stream_begin();
+          pp->dev = new AmgDevice();
+          pp->dev->upload(pp->res.levels, pp->res.cinv, pp->res.cbase, ap, max_m1, fine);
+          bk::side_stream_end();
+          pp->upload_secs = secs(t1, clk::now());
         } catch (std::exception& e) {
+          bk::side_stream_end();
           pp->res.err = e.what();
+        } catch (...) {
+          bk::side_stream_end();
+          pp->res.err = "GenEO: level-1 hierarchy set-up failed";
         }
-        pp->res.secs = secs(t0, clk::now());
+        if (pp->res.secs == 0.0) pp->res.secs = secs(t0, clk::now());
       });
     };
     // The level-1 (A_Dir / A_Rob) hierarchy is not needed before the solve: host set-up on its own thread, joined

@@ -14,6 +14,50 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def raw_exchange_check(lib, comm, plan, dist):
+    """The two callbacks of the RCCL plan driven directly with two peers: forward (owners -> halos) and reverse (the
+    count arrays swap roles), widths 1, 5 and 32, every value tagged with its sender and its position in the sender's
+    buffer; the all-reduce; and the refusals (wider than the buffers, longer than the reduction buffer)."""
+    import ctypes as C
+    from geneo4petsc_amd.pc import GenEOPC
+    pc = GenEOPC(lib)
+    pc.set_sizes(12 ** 3, 2)
+    comm.attach(pc)
+    rank, size = plan.rank, plan.size
+    counts = [None] * size
+    dist.all_gather_object(counts, (np.asarray(plan.send_counts).tolist(), np.asarray(plan.recv_counts).tolist()))
+    send, recv, red = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.GeneoRcclPlanBuffers(comm.h, 0, C.byref(send), C.byref(recv), C.byref(red)) == 0
+    off = lambda c: np.concatenate([[0], np.cumsum(c)]).astype(int)
+    for reverse in (0, 1):
+        for w in (1, 5, 32):
+            outc = plan.recv_counts if reverse else plan.send_counts
+            inc = plan.send_counts if reverse else plan.recv_counts
+            nout = int(np.sum(outc))
+            src = (1000000.0 * (rank + 1) + np.arange(nout * w)).astype(np.float64)
+            lib.GeneoH2D(send, src.ctypes.data_as(C.c_void_p), src.nbytes)
+            assert lib.GeneoRcclPlanExchange(comm.h, 0, reverse | (w << 1)) == 0, lib.GeneoRcclGetError().decode()
+            got = np.zeros(int(np.sum(inc)) * w)
+            lib.GeneoD2H(got.ctypes.data_as(C.c_void_p), recv, got.nbytes)
+            io = off(inc)
+            for q in range(size):
+                qout = counts[q][1] if reverse else counts[q][0]       # what q sends in this direction, per peer
+                qo = off(qout)
+                want = 1000000.0 * (q + 1) + np.arange(qo[rank] * w, qo[rank + 1] * w)
+                np.testing.assert_array_equal(got[io[q] * w:io[q + 1] * w], want)
+    vals = np.random.default_rng(rank).random(1000)
+    allv = [None] * size
+    dist.all_gather_object(allv, vals)
+    lib.GeneoH2D(red, vals.ctypes.data_as(C.c_void_p), vals.nbytes)
+    assert lib.GeneoRcclPlanAllreduce(comm.h, 0, 1000) == 0, lib.GeneoRcclGetError().decode()
+    got = np.zeros(1000)
+    lib.GeneoD2H(got.ctypes.data_as(C.c_void_p), red, got.nbytes)
+    np.testing.assert_array_equal(got, sum(allv[1:], allv[0]))
+    assert lib.GeneoRcclPlanExchange(comm.h, 0, 0 | (64 << 1)) != 0           # wider than the buffers: refused on every rank
+    assert lib.GeneoRcclPlanAllreduce(comm.h, 0, (1 << 16) + 1) != 0           # longer than the reduction buffer: refused
+    pc.destroy()
+
+
 def main():
     out_path, lvl, ksp = sys.argv[1], sys.argv[2], sys.argv[3]
     parts = tuple(int(t) for t in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 2, 2)
@@ -39,6 +83,13 @@ def main():
         from geneo4petsc_amd.comm import StagedComm
         lib = hu.hostsim_lib()
         comm = StagedComm(plan, lib)
+    elif os.environ.get("GENEO_WORKER_LIB") == "rccl_standin":
+        # the library's C++ RCCL transport (csrc/comm_rccl.cpp) with two peers: GENEO_RCCL_LIBRARY binds the test-only
+        # shared-memory stand-in of librccl; gloo only carries the 128-byte unique id and the test's own gathers
+        from geneo4petsc_amd.comm import RcclComm
+        lib = hu.hostsim_lib()
+        comm = RcclComm(plan, lib, dist, "cpu")
+        raw_exchange_check(lib, comm, plan, dist)
     else:
         lib = hu.hostsim_lib()
         comm = TorchComm(plan, "cpu")

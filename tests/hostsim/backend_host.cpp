@@ -22,6 +22,8 @@ const char* name() { return "hostsim"; }
 void set_stream(void* s) { g_stream = s; }
 void* get_stream() { return g_stream; }
 void sync() {}
+void side_stream_begin() {}
+void side_stream_end() {}
 
 void* alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { free(p); }

@@ -14,6 +14,16 @@ from oracle import geneo_oracle as go
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    """a free rendezvous port per test (a fixed one collides with concurrent jobs on the same host)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 @pytest.mark.parametrize("lvl,ksp,parts,extra", [
     ("ASM,1", "cg", (2, 2, 2), []), ("RAS,H1", "gmres", (2, 2, 2), []),
     ("SRAS,1", "cg", (2, 1, 1), []),        # ONE subdomain per rank: the layout of bench.py --gpus N (config 3)
@@ -24,7 +34,7 @@ def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     if lvl == "RAS,H1":
         env["GENEO_WORKER_LIB"] = "staged"     # same path through the host-staged transport (comm.StagedComm)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "gloo_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "gloo_worker.py"),
            out, lvl, ksp, ",".join(str(p) for p in parts)] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -54,7 +64,7 @@ def test_rccl_bootstrap_failure_is_collective():
     in the broadcast."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "tests", "rccl_bootstrap_worker.py")]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "rccl_bootstrap_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "OUTCOME " in r.stdout
