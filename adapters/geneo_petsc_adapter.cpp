@@ -187,10 +187,18 @@ PetscErrorCode setup(PC pc) {
       std::vector<int> owned((size_t)(re - rs)), halo, rc, sc, si;
       for (PetscInt g = rs; g < re; ++g) owned[(size_t)(g - rs)] = (int)g;
       ierr = halo_plan(PETSC_COMM_WORLD, rs, re, l2g, n, halo, rc, sc, si); CHKERRQ(ierr);
-      char id[128];
-      if (rank == 0 && GeneoRcclUniqueId(id)) SETERRQ1(PETSC_COMM_SELF, PETSC_ERR_LIB, "GenEO: %s", GeneoRcclGetError());
-      ierr = MPI_Bcast(id, 128, MPI_BYTE, 0, PETSC_COMM_WORLD); CHKERRQ(ierr);
-      if (GeneoRcclCreate(id, rank, size, &c->rccl)) SETERRQ1(PETSC_COMM_SELF, PETSC_ERR_LIB, "GenEO: %s", GeneoRcclGetError());
+      // Collective-safe bootstrap: every step is agreed on by all ranks before anyone raises, so that a rank failing
+      // alone (RCCL not loadable, communicator refused) never leaves the others waiting in a collective.
+      char id[129];
+      id[128] = (rank == 0 && GeneoRcclUniqueId(id)) ? 0 : 1;          // byte 128: rank 0 has an id
+      ierr = MPI_Bcast(id, 129, MPI_BYTE, 0, PETSC_COMM_WORLD); CHKERRQ(ierr);
+      if (!id[128]) SETERRQ1(PETSC_COMM_WORLD, PETSC_ERR_LIB, "GenEO: rank 0 could not create the RCCL unique id: %s", rank == 0 ? GeneoRcclGetError() : "see rank 0");
+      int made = GeneoRcclCreate(id, rank, size, &c->rccl) ? 0 : 1, all_made = 0;
+      ierr = MPI_Allreduce(&made, &all_made, 1, MPI_INT, MPI_MIN, PETSC_COMM_WORLD); CHKERRQ(ierr);
+      if (!all_made) {
+        if (made) GeneoRcclDestroy(&c->rccl);
+        SETERRQ1(PETSC_COMM_WORLD, PETSC_ERR_LIB, "GenEO: RCCL communicator creation failed on at least one rank: %s", made ? "another rank" : GeneoRcclGetError());
+      }
       if (PCGenEOSetCommRccl(c->h, c->rccl, (int)owned.size(), owned.data(), (int)halo.size(), halo.data(), rc.data(),
                              sc.data(), si.data(), 32))
         SETERRQ1(PETSC_COMM_SELF, PETSC_ERR_LIB, "GenEO: %s", GeneoRcclGetError());
@@ -289,6 +297,17 @@ PETSC_EXTERN PetscErrorCode createGenEOPC(PC pcPC) {       // hdr/geneo_c.h:9, g
   c->lvl2ApplyTimeLoc = c->lvl2ApplyZtTimeLoc = c->lvl2ApplyEinvTimeLoc = c->lvl2ApplyZTimeLoc = 0.;
   c->check = c->checkBin = c->checkMat = false;
   c->debug = 0; c->debugBin = c->debugMat = false;
+  // One process per GPU: the rank inside the node picks the device, before the library allocates anything or RCCL
+  // sees this process (ncclCommInitRank refuses two ranks on one device).  GENEO_KEEP_DEVICE=1: the launcher has bound
+  // the ranks already (HIP_VISIBLE_DEVICES per rank).
+  if (!getenv("GENEO_KEEP_DEVICE")) {
+    MPI_Comm node;
+    PetscMPIInt local = 0;
+    PetscErrorCode ierr0 = MPI_Comm_split_type(PETSC_COMM_WORLD, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &node); CHKERRQ(ierr0);
+    ierr0 = MPI_Comm_rank(node, &local); CHKERRQ(ierr0);
+    ierr0 = MPI_Comm_free(&node); CHKERRQ(ierr0);
+    if (GeneoSetDevice((int)local) < 0) { delete c; SETERRQ(PETSC_COMM_SELF, PETSC_ERR_LIB, "GenEO: no MI355X visible to this rank"); }
+  }
   if (PCCreate_GenEO(&c->h)) { delete c; SETERRQ(PETSC_COMM_WORLD, PETSC_ERR_LIB, "GenEO: cannot create the library context"); }
   refresh_parameters(c);
   // The driver asks the level-1 KSP's PC for its factor solver type (driver:946-957).  The local solves live in the

@@ -34,7 +34,8 @@ class GeneoInfo(C.Structure):
                                           "lvl1ApplyMinvTimeLoc", "lvl1ApplyGatherTimeLoc",
                                           "lvl1ApplyPrjFSTimeLoc", "lvl2ApplyTimeLoc", "lvl2ApplyZtTimeLoc",
                                           "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")] + \
-               [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double)]
+               [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double),
+                ("nullPivotsLoc", C.c_int)]
 
 
 class GeneoInput(C.Structure):
@@ -99,6 +100,9 @@ SYMBOLS = {
                                C.c_longlong]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
+    "GeneoDeviceCount": (C.c_int, []),
+    "GeneoSetDevice": (C.c_int, [C.c_int]),
+    "GeneoAllocCacheRelease": (None, []),
     "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),
     "GeneoDeviceFree": (None, [C.c_void_p]),
     "GeneoH2D": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

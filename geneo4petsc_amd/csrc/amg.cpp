@@ -2,6 +2,7 @@
 #include "amg.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +15,9 @@
 #include "dense.h"
 
 namespace geneo {
+
+static std::atomic<int> g_null_pivots{0};     // null pivots fixed in the coarsest blocks since the last amg_null_pivots_take()
+int amg_null_pivots_take() { return g_null_pivots.exchange(0); }
 
 // ------------------------------------------------------------------------------ host sparse kernels
 // f(t, r0, r1) over contiguous row ranges on up to 16 host threads (serial below 20000 rows)
@@ -259,14 +263,14 @@ static void coarse_inverse(const HostCsr& CA, const std::vector<int>& csuboff, s
       for (int k = CA.rowptr[r0 + i]; k < CA.rowptr[r0 + i + 1]; ++k) a[(size_t)i * m + (CA.col[k] - r0)] += CA.val[k];
     for (int i = 0; i < m; ++i)
       for (int j = i + 1; j < m; ++j) a[(size_t)i * m + j] = a[(size_t)j * m + i] = 0.5 * (a[(size_t)i * m + j] + a[(size_t)j * m + i]);
+    // Singular blocks (a floating subdomain's Neumann matrix when the element matrices carry no mass term, --inpEps 0)
+    // get the reference's treatment of its MUMPS factors (tuneSolver, geneo.cpp:76-92): null pivots are detected and
+    // pinned, the V-cycle then applies a bounded generalised inverse instead of amplifying the kernel component of
+    // every residual by 1 / rounding.
     std::vector<double> l = a;
-    if (!dense::cholesky(l, m)) {
-      double tr = 0.0;
-      for (int i = 0; i < m; ++i) tr += a[(size_t)i * m + i];
-      l = a;
-      for (int i = 0; i < m; ++i) l[(size_t)i * m + i] += 1e-10 * tr / m;
-      if (!dense::cholesky(l, m)) throw std::runtime_error("AMG: coarsest block is not positive definite");
-    }
+    const int fixed = dense::cholesky_fix_null_pivots(l, m);
+    if (fixed < 0) throw std::runtime_error("AMG: coarsest block is not positive semi-definite");
+    if (fixed > 0) g_null_pivots.fetch_add(fixed);
     std::vector<double> e(m);
     double* inv = coarse_inv.data() + coarse_base[s];
     for (int j = 0; j < m; ++j) {
@@ -699,7 +703,10 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
     // damped-Jacobi V-cycle in 4 launches per level: the vector passes ride on the SpMV / SpMM epilogues
     const double w = jacobi_weight(L);
     const bk::Csr& Apre = L.Acs.n ? L.Acs : L.A;
-    const bool vec = (m == 1 && ldb <= 1 && ldx <= 1);     // contiguous single vectors: the companions apply
+    // contiguous single vectors: the single-precision companions apply -- only when the hierarchy was asked to use them
+    // (-dls1_amg_precision single): a borrowed level-0 matrix may carry a companion for its owner's own purposes (the
+    // 16-bit column offsets of the FP64 SpMV), which must not turn a "double" V-cycle into a float one
+    const bool vec = (m == 1 && ldb <= 1 && ldx <= 1) && prm.single;
     // with the post-smoothing matrix x1 = w D^-1 b is never read back (EPI_POST rebuilds it from b): it is not stored
     double* X1 = L.M.n ? nullptr : X;
     if (vec && bk::csr_has_lp(Apre)) bk::spmv_fused_lp(Apre, bk::EPI_PRE, nullptr, L.r, B, X1, L.dinv, w);

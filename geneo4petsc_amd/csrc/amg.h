@@ -37,6 +37,10 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
                     std::vector<AmgLevelHost>& levels, std::vector<double>& coarse_inv,
                     std::vector<int64_t>& coarse_base);
 
+// null pivots detected and fixed in the dense coarsest blocks (singular subdomain matrices: tuneSolver, geneo.cpp:76-92)
+// by the hierarchies built since the last call
+int amg_null_pivots_take();
+
 // Device hierarchy + V-cycle on row-major blocks of m vectors (m = 1: SpMV kernels).
 class AmgDevice {
  public:

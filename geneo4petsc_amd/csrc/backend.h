@@ -27,6 +27,8 @@ void sync();                              // wait for the calling thread's strea
 void side_stream_begin();
 void side_stream_end();
 
+int   device_count();                     // GPUs visible to this process
+int   set_device(int ordinal);            // binds the calling thread's (and the library's) work to that GPU; returns it, -1 on failure
 void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
 void  dfree(void* p);
 void  alloc_cache_release();   // hipFree every block the caching allocator holds (backend_hip.hip: alloc)

@@ -87,6 +87,18 @@ void side_stream_end() {
 void* get_stream() { return (void*)g_stream; }
 void sync() { HIPCHK(hipStreamSynchronize(g_stream)); }
 
+int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+int set_device(int ordinal) {
+  const int n = device_count();
+  if (n <= 0 || ordinal < 0) return -1;
+  const int d = ordinal % n;
+  if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return d;
+}
 static double g_alloc_s = 0.0, g_free_s = 0.0;
 static long long g_alloc_n = 0;
 // Caching allocator.  hipMalloc of a multi-GB block costs ~18 ms per GB on this system (184^3 per GPU: 0.9 s of a 2.5 s

@@ -347,6 +347,7 @@ PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* o) {
   o->lvl2ApplyZtTimeLoc = i.lvl2ApplyZtTimeLoc; o->lvl2ApplyEinvTimeLoc = i.lvl2ApplyEinvTimeLoc;
   o->lvl2ApplyZTimeLoc = i.lvl2ApplyZTimeLoc; o->setupTime = i.setupTime; o->solveTime = i.solveTime;
   o->amg_levels = i.amg_levels; o->amg_operator_complexity = i.amg_operator_complexity; o->amgSetupTime = i.amgSetupTime;
+  o->nullPivotsLoc = i.nullPivotsLoc;
   return 0;
 }
 static int copy_out(const std::vector<double>& v, double* out, int cap) {
@@ -453,6 +454,9 @@ PetscErrorCode GeneoSetStream(void* s) {
   bk::set_stream(s);
   return 0;
 }
+int GeneoDeviceCount(void) { return bk::device_count(); }
+int GeneoSetDevice(int local_rank) { return bk::set_device(local_rank); }
+void GeneoAllocCacheRelease(void) { bk::alloc_cache_release(); }
 void* GeneoDeviceAlloc(size_t bytes) {
   try {
     return bk::alloc(bytes);

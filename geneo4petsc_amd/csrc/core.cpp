@@ -287,8 +287,19 @@ static void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t
     return;
   }
   std::vector<std::thread> th;
-  for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() { f(n * t / nth, n * (t + 1) / nth); });
+  std::exception_ptr err;
+  std::mutex mu;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      try {
+        f(n * t / nth, n * (t + 1) / nth);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!err) err = std::current_exception();
+      }
+    });
   for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 int PC::build_layout() {
@@ -572,6 +583,7 @@ int PC::setup(const double* b_dev) {
   // allocated; the clock of setupTime starts after that release
   free_all();
   info = Info();
+  (void)amg_null_pivots_take();
   auto t0 = clk::now();
   std::string err = validate_options(opt);
   if (!err.empty()) return fail(err);
@@ -601,7 +613,14 @@ int PC::setup(const double* b_dev) {
   auto t1 = clk::now();
   // the level-1 block-diagonal matrix is assembled on its own thread while this one assembles and uploads A_Neu
   HostCsr h_dirL;
-  std::thread dir_thread([&]() { h_dirL = make_blockdiag(lvl1, suboff, nullptr); });
+  std::exception_ptr dir_err;      // a bad_alloc on the thread must come back as an error code, not std::terminate
+  std::thread dir_thread([&]() {
+    try {
+      h_dirL = make_blockdiag(lvl1, suboff, nullptr);
+    } catch (...) {
+      dir_err = std::current_exception();
+    }
+  });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } dir_joiner{dir_thread};
   HostCsr h_neuL = make_blockdiag(neu, suboff, nullptr);
   const bool want1 = (opt.dls1_pc == "amg");
@@ -623,6 +642,13 @@ int PC::setup(const double* b_dev) {
   neuE = bk::csr_remap_columns(neuL, d_l2e);
   lap("ext-space copy");
   dir_thread.join();
+  if (dir_err) {
+    try {
+      std::rethrow_exception(dir_err);
+    } catch (std::exception& e) {
+      return fail(std::string("GenEO preconditioner: level-1 matrix assembly failed: ") + e.what());
+    }
+  }
   lap("A_Dir blockdiag (joined)");
   dirL = upload_host(h_dirL);
   dirL.fine = true;
@@ -781,6 +807,9 @@ int PC::setup(const double* b_dev) {
     }
   }
   bk::sync();
+  info.nullPivotsLoc = amg_null_pivots_take();
+  if (info.nullPivotsLoc && getenv("GENEO_DEBUG"))
+    fprintf(stderr, "[setup] %d null pivot(s) detected and fixed in the coarsest blocks of the local hierarchies (singular subdomain matrix)\n", info.nullPivotsLoc);
   info.setupTime = secs(t0, clk::now());
   if (getenv("GENEO_DEBUG")) {
     double as = 0, fs = 0;
@@ -1257,6 +1286,16 @@ class HostPool {
       for (int s = s0; s < s1; ++s) f(s);
       return;
     }
+    // one work list at a time: a second PC setting up on another host thread waits here; a nested run() from inside a
+    // work item runs its items inline (the pool is busy with the outer list)
+    std::unique_lock<std::mutex> one(run_mu, std::try_to_lock);
+    if (!one.owns_lock()) {
+      if (in_pool_work) {
+        for (int s = s0; s < s1; ++s) f(s);
+        return;
+      }
+      one.lock();
+    }
     std::exception_ptr err;
     {
       std::unique_lock<std::mutex> lk(mu);
@@ -1311,17 +1350,21 @@ class HostPool {
         s = next++;
         f = fn;
       }
+      in_pool_work = true;
       try {
         (*f)(s);
       } catch (...) {
         std::unique_lock<std::mutex> lk(mu);
         if (perr && !*perr) *perr = std::current_exception();
       }
+      in_pool_work = false;
       std::unique_lock<std::mutex> lk(mu);
       if (--pending == 0) done_cv.notify_all();
     }
   }
   std::vector<std::thread> workers;
+  std::mutex run_mu;
+  static thread_local bool in_pool_work;
   std::mutex mu;
   std::condition_variable cv, done_cv;
   const std::function<void(int)>* fn = nullptr;
@@ -1330,6 +1373,8 @@ class HostPool {
   unsigned long long generation = 0;
   bool stop = false;
 };
+
+thread_local bool HostPool::in_pool_work = false;
 
 // LOBPCG on a pencil A v = lambda B v (lowest eigenvalues) for all local subdomains in lock step.
 // Basis S = [X | P | W] (n_L x 3m row-major).  Per iteration and subdomain:
@@ -1572,7 +1617,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   bk::block_axpby(AS + m, p3, 0.0, AS + m, p3, 0.0, nL, m);
   bk::block_axpby(BS + m, p3, 0.0, BS + m, p3, 0.0, nL, m);
 
-  const double tol = opt.eps_tol;
+  const double tol = P.tol > 0.0 ? P.tol : opt.eps_tol;
   const double lmax = P.lmax * 1.05, lmin = lmax / std::max(1.5, opt.cheb_ratio);
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
   // Convergence test (-els2_eps_conv):
@@ -2032,6 +2077,16 @@ int PC::eigen_lobpcg() {
       mm = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
     }
     // ---- deflated restarts: 64-column blocks, 48 pairs asked per stage
+    // Locked vectors define the space every later stage works in: an error of size tol in them comes back at first
+    // order in the vectors of the later stages.  The stages therefore run at min(-els2_eps_tol, 1e-8), the first one
+    // again from its start block (with a loose -els2_eps_tol the reference's ARPACK, asked for ALL these pairs at
+    // once, returns most of them far below the tolerance as well; round 2 handed such subdomains to a dense solver).
+    const double tight = std::min(opt.eps_tol, 1e-8);
+    if (tight < opt.eps_tol) {
+      P.tol = tight;
+      P.nev_try = nev;
+      if (int rc = lobpcg_solve(P, mm, cur.lam, cur.X)) { bk::dfree(cur.X); return rc; }
+    }
     std::vector<EigProblem::Locked> locked_blocks;
     std::vector<int> locked_cols(ns, 0);
     std::vector<char> skip(ns, 0);

@@ -76,6 +76,7 @@ struct Info {                 // public counters / timers of geneoContext (hdr/g
   long long spmv_calls = 0;
   int amg_levels = 0, amg_on_device = 0;
   double amg_operator_complexity = 0.0, amgSetupTime = 0.0;
+  int nullPivotsLoc = 0;
 };
 
 struct KspResult {
@@ -191,6 +192,7 @@ class PC {
     const char* skip = nullptr;
     const int* locked_cols = nullptr;     // per subdomain: columns locked so far (bounds the pairs that can still be asked for)
     int seed_off = 0;
+    double tol = 0.0;                     // > 0: convergence tolerance of this solve instead of -els2_eps_tol
   };
   int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
   int eig_targets(int* nev_try) const;

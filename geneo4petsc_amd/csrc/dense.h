@@ -27,6 +27,37 @@ inline bool cholesky(std::vector<double>& a, int n) {
   }
   return true;
 }
+// Cholesky with NULL-PIVOT FIXING, the counterpart of what the reference asks of MUMPS for its local factorisations
+// (tuneSolver, geneo.cpp:76-92: ICNTL(24) = 1 detects null pivots, CNTL(5) = 1e20 replaces them by a huge value): a
+// pivot below tol * max|diag| is replaced by 1e20 * max|diag| and its column is not eliminated, so the matching unknown
+// comes out ~0 and the factor represents a bounded generalised inverse of a singular (e.g. pure Neumann) block.  On a
+// definite matrix no pivot is null and the result is bit-identical to cholesky().  Returns the number of fixed pivots,
+// -1 when a pivot is NEGATIVE beyond the threshold (indefinite matrix).
+inline int cholesky_fix_null_pivots(std::vector<double>& a, int n, double tol = 1e-12) {
+  double dmax = 0.0;
+  for (int j = 0; j < n; ++j) dmax = std::max(dmax, std::fabs(a[j * n + j]));
+  const double thr = tol * dmax;
+  int fixed = 0;
+  for (int j = 0; j < n; ++j) {
+    double d = a[j * n + j];
+    for (int k = 0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
+    if (d < -thr) return -1;
+    if (!(d > thr)) {                     // null pivot: pinned
+      ++fixed;
+      a[j * n + j] = 1e10 * std::sqrt(dmax > 0.0 ? dmax : 1.0);
+      for (int i = j + 1; i < n; ++i) a[i * n + j] = 0.0;
+      continue;
+    }
+    d = std::sqrt(d);
+    a[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = a[i * n + j];
+      for (int k = 0; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
+      a[i * n + j] = s / d;
+    }
+  }
+  return fixed;
+}
 // solve L L^T x = b in place
 inline void cholesky_solve(const std::vector<double>& l, int n, double* x) {
   for (int i = 0; i < n; ++i) {

@@ -187,6 +187,8 @@ typedef struct {
   double setupTime, solveTime;
   int amg_levels;                       /* levels of the inner AMG hierarchy (0 = not used) */
   double amg_operator_complexity, amgSetupTime;
+  int nullPivotsLoc;                    /* null pivots detected and fixed in the local factorisations of this set-up (singular
+                                           subdomain matrices; the reference's MUMPS settings of tuneSolver, geneo.cpp:76-92) */
 } GeneoInfo;
 PetscErrorCode PCGenEOGetInfo(GENEO_PC pc, GeneoInfo* info);
 /* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */
@@ -217,6 +219,15 @@ void GeneoFreeInput(GeneoInput* in);
 /* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
 const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */
 PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to this stream */
+/* One process per GPU: bind this process to GPU (local_rank mod GeneoDeviceCount()) BEFORE the first allocation, set-up
+ * or RCCL call (ncclCommInitRank refuses two ranks on one device).  Returns the device ordinal, -1 on failure.  The
+ * reference has no counterpart (CPU only); under mpirun pass the rank inside the node (MPI_Comm_split_type(SHARED)),
+ * as adapters/geneo_petsc_adapter.cpp does -- or give every rank its own HIP_VISIBLE_DEVICES and skip the call. */
+int GeneoDeviceCount(void);
+int GeneoSetDevice(int local_rank);
+/* hipFree every device block the library's caching allocator is holding (it keeps freed blocks for the next set-up, up
+ * to GENEO_ALLOC_CACHE_GB, default 96): call it when another allocator of the process needs the memory. */
+void GeneoAllocCacheRelease(void);
 void* GeneoDeviceAlloc(size_t bytes);
 void GeneoDeviceFree(void* p);
 PetscErrorCode GeneoH2D(void* dst_dev, const void* src, size_t bytes);

@@ -99,6 +99,7 @@ def graph_case(size=400, level=2, nb=4, overlap=1, no_ground=True):
     return mesh, dec, a, decomp.rhs_default(a)
 
 
+RECORD_MODE_HITS = []  # mismatches that GENEO_TEST_COUNT_DRIFT=record let through: a discovery run never ends green
 COUNT_DRIFT = []     # (case, library count, oracle count) of every declared / recorded iteration-count difference
 
 
@@ -120,14 +121,17 @@ def compare_with_oracle(lib, n, parts, overlap, argv, gen=None, with_dir=True, x
     # Iteration count: identical to the oracle's -- always for GMRES, and for CG unless the case is DECLARED
     # rounding-sensitive by its test (count_drift=(library count, oracle count), justified there).  Every use of
     # such a declaration is recorded in COUNT_DRIFT and printed in the terminal summary (tests/conftest.py), so a
-    # run shows which cases took it; an undeclared difference fails.  GENEO_TEST_COUNT_DRIFT=record turns the
-    # failure into a record (discovery runs on a new device only).
+    # run shows which cases took it; an undeclared difference fails.  GENEO_TEST_COUNT_DRIFT=record lets the run
+    # continue past such a failure to collect all of them (discovery on a new device); the SESSION still ends red
+    # (tests/conftest.py::pytest_sessionfinish).
     if its != res.its:
         label = "%s n=%s parts=%s overlap=%s %s" % (lib.GeneoBackendName().decode(), n, parts, overlap, " ".join(argv))
         COUNT_DRIFT.append((label, its, res.its))
         k = min(8, len(res.history), len(pc.residual_history()))
         np.testing.assert_allclose(pc.residual_history()[:k], res.history[:k], rtol=1e-8)
-        if os.environ.get("GENEO_TEST_COUNT_DRIFT") != "record":
+        if os.environ.get("GENEO_TEST_COUNT_DRIFT") == "record":
+            RECORD_MODE_HITS.append(label)       # tests/conftest.py turns the session red when this list is not empty
+        else:
             assert ksp == "cg", "GMRES iteration count differs: %d vs oracle %d" % (its, res.its)
             assert count_drift is not None, "undeclared CG iteration-count difference: %d vs oracle %d" % (its, res.its)
             assert (its, res.its) in count_drift, "CG count %d vs oracle %d is not the declared drift %r" % (

@@ -22,6 +22,8 @@ const char* name() { return "hostsim"; }
 void set_stream(void* s) { g_stream = s; }
 void* get_stream() { return g_stream; }
 void sync() {}
+int device_count() { return 0; }
+int set_device(int) { return -1; }
 void side_stream_begin() {}
 void side_stream_end() {}
 

@@ -48,6 +48,10 @@ typedef int MPI_Op;
 #define MPI_INT 1
 #define MPI_BYTE 2
 #define MPI_MAX 3
+#define MPI_MIN 4
+#define MPI_COMM_TYPE_SHARED 1
+typedef int MPI_Info;
+#define MPI_INFO_NULL 0
 #define MPI_IN_PLACE ((void*)1)
 PetscErrorCode PetscError(MPI_Comm, int, const char*, const char*, PetscErrorCode, int, const char*, ...);
 #define CHKERRQ(ierr) do { if (ierr) return (ierr); } while (0)
@@ -90,6 +94,8 @@ PetscErrorCode ISLocalToGlobalMappingRestoreIndices(ISLocalToGlobalMapping, cons
 int MPI_Comm_size(MPI_Comm, int*);
 int MPI_Comm_rank(MPI_Comm, int*);
 int MPI_Bcast(void*, int, MPI_Datatype, int, MPI_Comm);
+int MPI_Comm_split_type(MPI_Comm, int, int, MPI_Info, MPI_Comm*);
+int MPI_Comm_free(MPI_Comm*);
 int MPI_Allgather(const void*, int, MPI_Datatype, void*, int, MPI_Datatype, MPI_Comm);
 int MPI_Allreduce(const void*, void*, int, MPI_Datatype, MPI_Op, MPI_Comm);
 int MPI_Alltoall(const void*, int, MPI_Datatype, void*, int, MPI_Datatype, MPI_Comm);
