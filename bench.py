@@ -74,6 +74,15 @@ def build_parser():
     ap.add_argument("--pc-args", default="", help="further options for the PC")
     ap.add_argument("--cpu-sample-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="laplacian", choices=("laplacian", "heat", "graph"),
+                    help="laplacian: the metric's operator (default).  heat: BASELINE configs[3], tst/heat generator (lambda 1, "
+                         "dt 0.1, --kappa K minmax: kappa = K on the middle third of every axis, K = 100 => contrast K^3 = 1e6 in "
+                         "3-D), 8 subdomains; the step is timed with -geneo_lvl ASM,1 and the PCG count of plain ASM,0 is printed "
+                         "beside it.  graph: BASELINE configs[4], tst/graph generator --level 2 --noGround (--graph-size 1111111 "
+                         "=> 9 x 1054^2 = 10.0 M nodes), nodal partition into 8 by the library's C++ k-way partitioner (an "
+                         "irregular CSR: the LDS-tiled SpMV / SpMM stress).  Both N = 1 only.")
+    ap.add_argument("--kappa", type=float, default=100.0, help="heat: K of --kappa K minmax")
+    ap.add_argument("--graph-size", type=int, default=1111111, help="graph: --size of tst/graph (nodes = 9 floor(sqrt(size))^2 at level 2)")
     ap.add_argument("--one-rank-of", type=int, default=0, choices=(0, 8),
                     help="8: ONE rank's share of the metric's configuration on this one GPU, uncontended -- subdomain "
                          "--rank-index of the 2x2x2 decomposition of (2 n-per-gpu)^3 (default 368^3: 186^3 local rows, overlap 2, "
@@ -129,6 +138,50 @@ def build_problem(args, rank, size):
         sel = npart_of(d.l2g) == d.gid
         b[np.searchsorted(plan.owned, d.l2g[sel])] = rows[sel]
     return n, nb, spg, doms, plan, b
+
+
+class _WholePlan:
+    """the one-rank "plan" of an unstructured workload: this rank owns every DOF"""
+    def __init__(self, n):
+        self.owned = np.arange(n, dtype=np.int64)
+
+
+def build_problem_unstructured(args):
+    """heat / graph workloads (N = 1): (description, nDOF, nb, domains, plan, b, extra facts for the JSON line)"""
+    from geneo4petsc_amd import decomp
+    facts = {}
+    if args.workload == "heat":
+        n = args.n if args.n else (args.n_per_gpu or 126)
+        gen = dict(heat=True, lbd=1.0, dt=0.1, kappa_max=args.kappa, interp="minmax")
+        parts = (2, 2, 2)
+        doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, **gen) for s in range(8)]
+        ndof = n ** 3
+        # b = A (1..N) from the Dirichlet rows of the domain that owns each node (driver:820-831)
+        npart = decomp.structured_node_partition(n, 3, parts)
+        b = np.zeros(ndof)
+        for d in doms:
+            rows = d.a_dir @ (d.l2g.astype(np.float64) + 1.0)
+            sel = npart[d.l2g] == d.gid
+            b[d.l2g[sel]] = rows[sel]
+        desc = ("tst/heat generator (reference heat.cpp: lambda 1, dt 0.1, --kappa %g minmax => contrast %.0e), %d^3 = %d DoF, "
+                "8 subdomains (2x2x2), overlap %d" % (args.kappa, args.kappa ** 3, n, ndof, args.overlap))
+        return desc, ndof, 8, doms, _WholePlan(ndof), b, facts
+    t0 = time.perf_counter()
+    mesh = decomp.graph_mesh(size=args.graph_size, level=2, no_ground=True)
+    t1 = time.perf_counter()
+    ep, npart, cut = decomp.partition_mesh_native(mesh, 8, False)
+    t2 = time.perf_counter()
+    dec = decomp.decompose(mesh, 8, None, npart, False, args.overlap)
+    t3 = time.perf_counter()
+    a = decomp.global_matrix(mesh)
+    b = decomp.rhs_default(a)
+    counts = np.bincount(npart, minlength=8)
+    facts = {"generator_s": t1 - t0, "partition_s": t2 - t1, "decompose_s": t3 - t2, "partitioner": "csrc/partition.cpp "
+             "(GeneoPartMeshNodal: multilevel recursive bisection, the METIS_PartMeshNodal stand-in)", "edge_cut": int(cut),
+             "part_sizes": [int(c) for c in counts], "global_nnz": int(a.nnz)}
+    desc = ("tst/graph generator (reference graph.cpp: --size %d --level 2 --noGround), %d nodes, nodal k-way partition into 8 "
+            "(edge cut %d), overlap %d: irregular CSR" % (args.graph_size, mesh.nbNode, cut, args.overlap))
+    return desc, mesh.nbNode, 8, dec.domains, _WholePlan(mesh.nbNode), b, facts
 
 
 def cpu_baseline(args, doms, lib):
@@ -403,7 +456,15 @@ def main():
     lib.GeneoSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     t_prep = time.perf_counter()
-    n, nb, spg, doms, plan, b = build_problem(args, rank, size)
+    wl_desc, wl_facts = None, {}
+    if args.workload != "laplacian":
+        if size != 1:
+            raise SystemExit("--workload %s runs on one GPU (N = 1)" % args.workload)
+        wl_desc, ndof, nb, doms, plan, b, wl_facts = build_problem_unstructured(args)
+        n, spg = int(round(ndof ** (1.0 / 3.0))), 8
+    else:
+        n, nb, spg, doms, plan, b = build_problem(args, rank, size)
+        ndof = n ** 3
     comm = None
     comm_name = "none"
     if size > 1:
@@ -420,6 +481,8 @@ def main():
         else:
             comm, comm_name = gcomm.TorchComm(plan, torch.device("cuda", local_rank)), "torch.distributed (nccl backend)"
     prep_s = time.perf_counter() - t_prep
+    if args.workload == "heat" and args.lvl == "SRAS,1":
+        args.lvl = "ASM,1"          # configs[3]: GenEO coarse space (ASM,1) against plain ASM (ASM,0)
     argv = geneo_argv(args)
     bd = DeviceVector.from_host(lib, b)
 
@@ -427,7 +490,7 @@ def main():
     # subdomain matrices are handed over once, as in the reference's initGenEOPC, and only one set-up is alive at a time
     pc = GenEOPC(lib)
     pc.set_from_options(argv)
-    pc.set_sizes(n ** 3, nb)
+    pc.set_sizes(ndof, nb)
     if comm is not None:
         comm.attach(pc)
     for d in doms:
@@ -536,14 +599,18 @@ def main():
             "value": agg_gbs, "unit": "GB/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D 7-pt Laplacian (reference tst/laplacian generator, kappa=1, eps=1e-4; the reference has "
+            "config": {"workload": (wl_desc + ", -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e"
+                                    % (args.lvl, args.cut, args.tau, args.eps_tol, args.rtol)) if wl_desc else
+                                   "3D 7-pt Laplacian (reference tst/laplacian generator, kappa=1, eps=1e-4; the reference has "
                                    "no 27-pt generator), %d^3 = %d DoF, %d subdomains (%d per GPU), overlap %d, "
                                    "-geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e; %s"
                                    % (n, n ** 3, nb, spg, args.overlap, args.lvl, args.cut, args.tau, args.eps_tol, args.rtol,
                                       "N=1: BASELINE configs[1] size (126^3 = 2.0 M DoF) in 8 subdomains on the one GPU"
                                       if size == 1 else
                                       "N>1: the metric's configuration, 184^3 DoF and one subdomain per GPU (N=8: 368^3 = 49.8 M)"),
-                       "grid": n, "dof": n ** 3, "subdomains": nb, "subdomains_per_gpu": spg, "overlap": args.overlap,
+                       "workload_kind": args.workload, "workload_facts": wl_facts,
+                       "local_rows": info_rows, "local_nnz": int(sum(d.a_neu.nnz for d in doms)),
+                       "grid": n, "dof": ndof, "subdomains": nb, "subdomains_per_gpu": spg, "overlap": args.overlap,
                        "transport": comm_name,
                        "inner_solver": "local solves = AMG-PCG to -dls1_ksp_rtol %g in FP64 (the V-cycle streams float copies of "
                                        "its level matrices, -dls1_amg_precision single: FP64 arithmetic and vectors)" % args.dls1_rtol,
@@ -562,7 +629,22 @@ def main():
                                   "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
             "roofline": roof,
         }
-        if size == 1 and not args.no_cpu_baseline:
+        if args.workload == "heat":
+            # configs[3]: the same problem with plain one-level ASM (-geneo_lvl ASM,0), PCG iteration counts side by side
+            pc0 = GenEOPC(lib)
+            pc0.set_from_options([a if a != args.lvl else "ASM,0" for a in argv] + ["-ksp_max_it", "5000"])
+            pc0.set_sizes(ndof, nb)
+            for d in doms:
+                pc0.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+            pc0.setup(bd)
+            x0v, its0, _, reason0 = pc0.solve(bd)
+            i0 = pc0.info()
+            x0v.free()
+            pc0.destroy()
+            out["asm0_vs_geneo"] = {"ASM,0": {"iterations": int(its0), "converged": reason0, "setup_s": i0["setupTime"], "solve_s": i0["solveTime"]},
+                                    args.lvl: {"iterations": int(its), "converged": reason, "dimE": info["dimE"],
+                                               "setup_s": setup_s, "solve_s": solve_s}}
+        if size == 1 and not args.no_cpu_baseline and args.workload == "laplacian":
             try:
                 roof["spmv_hbm_resident"] = spmv_hbm_resident(lib, doms)
                 roof["spmv_hbm_resident"]["frac"] = roof["spmv_hbm_resident"]["GBs"] / HBM_PEAK_GBS

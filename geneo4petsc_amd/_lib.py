@@ -100,6 +100,9 @@ SYMBOLS = {
                                C.c_longlong]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
+    "GeneoPartMeshDual": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "GeneoPartMeshNodal": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "GeneoPartGraphKway": (C.c_int, [C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]),
     "GeneoDeviceCount": (C.c_int, []),
     "GeneoSetDevice": (C.c_int, [C.c_int]),
     "GeneoAllocCacheRelease": (None, []),

@@ -216,6 +216,18 @@ typedef struct {
 PetscErrorCode GeneoGetLibInput(const char* inpLibA, const char* inpLibArg, GeneoInput* out);
 void GeneoFreeInput(GeneoInput* in);
 
+/* ---- host k-way mesh partitioner (csrc/partition.cpp): what the reference's driver asks of Metis 5.1.0 --------------
+ * METIS_PartMeshDual(&ne, &nn, eptr, eind, NULL, NULL, &ncommon = 1, &nparts, NULL, options, &objval, epart, npart) and
+ * METIS_PartMeshNodal(&ne, &nn, eptr, eind, NULL, NULL, &nparts, NULL, options, &objval, epart, npart) with
+ * PTYPE_KWAY / OBJTYPE_CUT (src/geneo4PETSc.cpp:381-445).  Elements are node lists (eptr[ne + 1], eind[eptr[ne]]);
+ * epart[ne] / npart[nn] receive the parts; objval the edge cut of the partitioned graph.  Multilevel recursive bisection
+ * (heavy-edge matching, graph growing + spectral initial cuts, FM refinement, multilevel spectral candidate); sizes exact
+ * to one vertex per bisection; deterministic.  Host code only (no device is touched).  0 = ok. */
+int GeneoPartMeshDual(int ne, int nn, const int* eptr, const int* eind, int nparts, int* objval, int* epart, int* npart);
+int GeneoPartMeshNodal(int ne, int nn, const int* eptr, const int* eind, int nparts, int* objval, int* epart, int* npart);
+/* METIS_PartGraphKway on a CSR graph (symmetric adjacency, no self loops, unit weights) */
+int GeneoPartGraphKway(int n, const int* xadj, const int* adjncy, int nparts, int* objval, int* part);
+
 /* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
 const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */
 PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to this stream */

@@ -139,3 +139,51 @@ def test_partitioner_handles_disconnected_and_tiny_graphs():
     assert sorted(np.bincount(p).tolist()) == [2, 2, 3]
     with pytest.raises(ValueError):
         decomp.partition_graph(g, 8)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("n,k", [(10, 8), (9, 5), (20, 8)])
+def test_native_kway_partitioner(n, k, dual):
+    """The library's C++ partitioner (csrc/partition.cpp, GeneoPartMeshDual / Nodal behind the C ABI: the counterparts of
+    the driver's METIS_PartMeshDual / METIS_PartMeshNodal calls, src/geneo4PETSc.cpp:381-445): sizes exact to one vertex
+    per bisection, every part non-empty, deterministic, the cut of the structured 2x2x2 blocks on a cube (the optimum)
+    and within 1.1x of the numpy / scipy prototype it was ported from; the second output follows the first."""
+    mesh = decomp.grid_mesh(size=n, dim=3)
+    g = decomp.mesh_graph(mesh, dual)
+    ep, npt, cut = decomp.partition_mesh_native(mesh, k, dual)
+    p = ep if dual else npt
+    sizes = np.bincount(p, minlength=k)
+    assert sizes.min() >= 1 and sizes.max() - sizes.min() <= max(2, int(np.ceil(np.log2(k))) + 1)
+    assert cut == decomp.edge_cut(g, p)
+    ep2, npt2, cut2 = decomp.partition_mesh_native(mesh, k, dual)
+    assert np.array_equal(ep, ep2) and np.array_equal(npt, npt2) and cut == cut2
+    assert cut <= 1.1 * decomp.edge_cut(g, decomp.partition_graph(g, k))
+    if not dual and k == 8:
+        nn = decomp.grid_size(n, 1, 3)
+        assert cut <= 1.05 * decomp.edge_cut(g, decomp.structured_node_partition(nn, 3, (2, 2, 2)))
+    # the other kind of object follows the partitioned one (a node the part of one of its elements, and vice versa)
+    e, w = np.nonzero(mesh.nodes >= 0)
+    if dual:
+        ok = np.zeros(mesh.nbNode, dtype=bool)
+        ok[mesh.nodes[e, w][ep[e] == npt[mesh.nodes[e, w]]]] = True
+        assert ok.all()
+    else:
+        assert (ep == npt[mesh.nodes[:, 0]]).all()
+    dec = decomp.decompose(mesh, k, ep if dual else None, None if dual else npt, dual, 1)
+    assert len(dec.domains) == k and all(len(d.l2g) > 0 for d in dec.domains)
+
+
+def test_native_partitioner_irregular_graph_and_csr_entry():
+    """tst/graph input (configs[4] in small): GeneoPartGraphKway on the nodal graph == GeneoPartMeshNodal on the mesh;
+    one part and more parts than vertices behave as the Metis wrapper of the driver expects (driver:397-400)."""
+    mesh = decomp.graph_mesh(size=900, level=2, no_ground=True)
+    g = decomp.mesh_graph(mesh, False)
+    _, npt, cut = decomp.partition_mesh_native(mesh, 8, False)
+    p = decomp.partition_graph_native(g, 8)
+    assert np.array_equal(p, npt) and decomp.edge_cut(g, p) == cut
+    sizes = np.bincount(p, minlength=8)
+    assert sizes.max() - sizes.min() <= 4
+    assert cut <= 1.1 * decomp.edge_cut(g, decomp.partition_graph(g, 8))
+    assert (decomp.partition_graph_native(g, 1) == 0).all()
+    with pytest.raises(RuntimeError):
+        decomp.partition_graph_native(g, g.shape[0] + 1)

@@ -271,3 +271,14 @@ def test_no_cut_more_eigenvalues_below_tau_than_one_block_holds(lib):
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.6", "-ksp_type", "gmres"] + TIGHT
     _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv)
     assert info["dimE"] == 632 and info["realDimELoc"] == 632
+
+
+def test_singular_neumann_matrices_get_null_pivot_fixing(lib):
+    """--inpEps 0: the Neumann matrices of the four subdomains away from the Dirichlet face are singular (pure Neumann
+    Laplacians).  The reference tells MUMPS to detect null pivots and fix them (tuneSolver, geneo.cpp:76-92: ICNTL(24),
+    CNTL(5) = 1e20) for exactly this; here the coarsest blocks of the hierarchies pin them the same way
+    (dense::cholesky_fix_null_pivots) -- without it the V-cycle amplifies the kernel component of every residual by
+    1 / rounding and LOBPCG never converges.  Counts, eigenvalues (the exact zeros included) and GMRES count == oracle."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "gmres"] + TIGHT
+    _, info = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, argv, gen=dict(inp_eps=0.0))
+    assert info["nullPivotsLoc"] >= 4
