@@ -91,6 +91,8 @@ def build_parser():
                          "preconditioner + local SpMV (what one PCG iteration costs this rank between two halo exchanges)")
     ap.add_argument("--rank-index", type=int, default=0)
     ap.add_argument("--apply-count", type=int, default=25)
+    ap.add_argument("--no-anchor", action="store_true",
+                    help="N > 1: skip the one-GPU anchor (184^3 in 8 subdomains on rank 0's GPU after the timed region)")
     ap.add_argument("--comm", default=os.environ.get("GENEO_BENCH_COMM", "rccl"), choices=("rccl", "torch", "staged"),
                     help="N > 1 transport: rccl = C++ ncclSend/Recv + ncclAllReduce inside libgeneopc (default); "
                          "torch = torch.distributed callbacks; staged = host-staged gloo (ranks may share a GPU)")
@@ -363,6 +365,43 @@ def one_rank_of(args):
     pc.destroy()
 
 
+def one_gpu_anchor(args, lib, torch):
+    from geneo4petsc_amd import decomp
+    from geneo4petsc_amd.pc import GenEOPC, DeviceVector
+    n = args.n_per_gpu or 184
+    parts = (2, 2, 2)
+    t0 = time.perf_counter()
+    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s) for s in range(8)]
+    npart = decomp.structured_node_partition(n, 3, parts)
+    b = np.zeros(n ** 3)
+    for d in doms:
+        rows = d.a_dir @ (d.l2g.astype(np.float64) + 1.0)
+        sel = npart[d.l2g] == d.gid
+        b[d.l2g[sel]] = rows[sel]
+    prep = time.perf_counter() - t0
+    pc = GenEOPC(lib)
+    pc.set_from_options(geneo_argv(args))
+    pc.set_sizes(n ** 3, 8)
+    for d in doms:
+        pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+    bd = DeviceVector.from_host(lib, b)
+    res = None
+    for _ in range(2):               # one warm-up, one measured step
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        pc.setup(bd)
+        x, its, _, reason = pc.solve(bd)
+        torch.cuda.synchronize()
+        info = pc.info()
+        x.free()
+        res = {"workload": "%d^3 = %d DoF in 8 subdomains on ONE GPU (the per-GPU DoF count of the N > 1 runs)" % (n, n ** 3),
+               "setup_s": info["setupTime"], "solve_s": info["solveTime"], "setup_plus_solve_s": info["setupTime"] + info["solveTime"],
+               "wall_s": time.perf_counter() - tw, "iterations": int(its), "converged": reason, "dimE": info["dimE"],
+               "host_prep_s": prep}
+    pc.destroy()
+    return res
+
+
 def spawn(args):
     """N > 1 without torchrun: start the ranks as CHILD processes (this parent never touches the GPU) and relay."""
     s = socket.socket()
@@ -508,8 +547,15 @@ def main():
         x.free()
         return its, reason, info
 
-    for _ in range(args.warmup):
-        step()
+    first_setup = None
+    for w in range(args.warmup):
+        tw = time.perf_counter()
+        fi = step()[2]
+        if w == 0:      # the first set-up of the process: the allocator is empty, every device block comes from hipMalloc
+            torch.cuda.synchronize()
+            first_setup = {"setup": fi["setupTime"], "solve": fi["solveTime"], "wall": time.perf_counter() - tw,
+                           "note": "first set-up of the process (allocator empty, hipMalloc included); the timed steps re-set-up "
+                                   "the same PC on cached device blocks"}
     # in-situ kernel timer: every 4th launch of each hot kernel class (fine-level SpMV / SpMM, MFMA Gram and update)
     lib.GeneoKernelProfileStart(4, C.c_double(0.0))
     barrier()
@@ -566,25 +612,36 @@ def main():
         # launches each kernel class on this matrix / these block shapes; the in-situ launches of a class mix variants
         # (epilogues, widths), so the measured RATIO traffic / algorithmic of the class is applied to the in-situ
         # algorithmic bytes per launch.
+        # The file names the kernel source it was measured on (sha256 of csrc/backend_hip.hip): a profile older than the
+        # kernels is NOT applied -- traffic stays null and the line says why.
+        traffic_note = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")))
+            import hashlib
+            pmc_path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.json")
+            prof = json.load(open(pmc_path))
+            sha = hashlib.sha256(open(os.path.join(ROOT, "geneo4petsc_amd", "csrc", "backend_hip.hip"), "rb").read()).hexdigest()[:16]
+            if prof.get("kernel_source_sha16") != sha:
+                traffic_note = ("profiles/r03_hbm_traffic_pmc.json was measured on kernel source %s, this is %s: stale, not applied"
+                                % (prof.get("kernel_source_sha16"), sha))
+                print("bench.py: " + traffic_note, file=sys.stderr, flush=True)
+                prof = {}
             for k in kernels:
                 key = k["kernel"].split(" ")[0]
                 hits = [v for name, v in prof.items() if isinstance(v, dict) and name.startswith(key) and "traffic_over_algorithmic" in v]
                 if hits and abs(hits[0].get("rows", info_rows) - info_rows) <= 0.01 * info_rows:
                     k["traffic_over_algorithmic"] = hits[0]["traffic_over_algorithmic"]
                     k["traffic"] = hits[0]["traffic_over_algorithmic"] * k["algorithmic_bytes_per_launch"]
-        except Exception:
-            pass
+        except Exception as e:
+            traffic_note = "no PMC profile applied: %r" % (e,)
         dom = max(kernels, key=lambda k: k["share_of_step"]) if kernels else None
         roof = {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS,
                 "traffic": None, "kernel": "k_spmv_sell"}
         if dom is not None:
             roof = {"bound": "hbm", "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-                    "traffic_source": ("profiles/r02_hbm_traffic_pmc.json: PMC traffic / algorithmic of this kernel class "
-                                       "(%.3f) x the in-situ algorithmic bytes per launch" % dom["traffic_over_algorithmic"])
-                    if dom.get("traffic") else None,
+                    "traffic_source": ("profiles/r03_hbm_traffic_pmc.json (same kernel source): PMC traffic / algorithmic of this "
+                                       "kernel class (%.3f) x the in-situ algorithmic bytes per launch" % dom["traffic_over_algorithmic"])
+                    if dom.get("traffic") else traffic_note,
                     "kernel": dom["kernel"], "share_of_step": dom["share_of_step"],
                     "avg_launch_ms": dom["avg_launch_ms"], "launches_timed": dom["launches_timed"],
                     "launches_total": dom["launches_total"],
@@ -616,7 +673,7 @@ def main():
                                        "its level matrices, -dls1_amg_precision single: FP64 arithmetic and vectors)" % args.dls1_rtol,
                        "allocator": "device blocks are cached across set-ups (the timed steps re-set-up one PC: no hipMalloc "
                                     "inside them after the warm-up step)"},
-            "setup_s": setup_s, "solve_s": solve_s, "setup_plus_solve_s": setup_s + solve_s,
+            "setup_s": setup_s, "solve_s": solve_s, "setup_plus_solve_s": setup_s + solve_s, "first_setup_s": first_setup,
             "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
             "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
             "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
@@ -653,8 +710,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, doms, lib)
             if "parity_sample" in out["cpu_baseline"]:
                 out["parity_sample"] = out["cpu_baseline"].pop("parity_sample")
-        print(json.dumps(out), flush=True)
     pc.destroy()
+    if rank == 0:
+        if size > 1 and not args.no_anchor:
+            # The weak-scaling curve compares N GPUs x (184^3, ONE subdomain each) with ... what on one GPU?  bench.py's N = 1
+            # line is 126^3 in 8 subdomains (BASELINE configs[1]); the like-for-like anchor -- the SAME per-GPU DoF count on
+            # one GPU, where the two-level method needs several subdomains -- is 184^3 in 8 subdomains, run here on rank 0's
+            # GPU after the timed region (the other ranks wait at the barrier below).
+            try:
+                out["one_gpu_anchor"] = one_gpu_anchor(args, lib, torch)
+            except Exception as e:
+                out["one_gpu_anchor"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
     if comm is not None and hasattr(comm, "close"):
         comm.close()
     if dist is not None:

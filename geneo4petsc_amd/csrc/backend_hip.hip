@@ -1034,6 +1034,50 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ s
   const int r = 64 * s + l;
   if (r < n) y[r] = sum;
 }
+
+// The same traversal with EIGHT predicated k-steps per round: a slice of a 7-point matrix is 7 entries wide, and with
+// the 4-step loop above its last three entries go through the one-at-a-time tail -- three more dependent
+// (col -> x) latency pairs per wave.  Here every (col, val) pair of the slice is requested before the first x gather
+// and all gathers are in flight together: two dependent latencies per slice.  Lanes past the slice's width load nothing
+// (predicated), so no extra traffic.
+template <bool NT, typename COLT = int>
+__global__ __launch_bounds__(256) void k_spmv_sell_p8(const int64_t* __restrict__ sl_ptr, int nslice, int n,
+                                                      const COLT* __restrict__ col, const double* __restrict__ val,
+                                                      const double* __restrict__ x, double* __restrict__ y,
+                                                      const int* __restrict__ cbase = nullptr) {
+  const int nwb = (nslice + 3) >> 2;
+  const int t = xcd_remap(blockIdx.x, nwb);
+  const int s = 4 * t + (threadIdx.x >> 6);
+  if (t >= nwb || s >= nslice) return;
+  const int l = threadIdx.x & 63;
+  const int64_t a = sl_ptr[s], b = sl_ptr[s + 1];
+  const int cb = cbase ? cbase[s] : 0;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int64_t e = a + l; e < b; e += 64 * 8) {
+    int c[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = e + 64 * u < b;
+      c[u] = cb;
+      v[u] = 0.0;
+      if (ok) {
+        c[u] = cb + (int)(NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u]);
+        v[u] = NT ? __builtin_nontemporal_load(val + e + 64 * u) : val[e + 64 * u];
+      }
+    }
+    double xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc0 += v[u] * xv[u];
+      acc1 += v[u + 1] * xv[u + 1];
+    }
+  }
+  const int r = 64 * s + l;
+  if (r < n) y[r] = acc0 + acc1;
+}
 // Same traversal with the multigrid epilogues of backend.h fused in (EPI_RES / ADD / JAC / PRE): the vector
 // passes that used to follow the SpMV (residual, correction, Jacobi update) ride on its output write.
 template <bool NT, int EPI>
@@ -1549,9 +1593,16 @@ void spmv(const Csr& a, const double* x, double* y) {
     // 42.2 us without; back-to-back re-reads of the same matrix (a micro-benchmark, not the solver's
     // access pattern) prefer the cached stream, which is why small (coarse-level) matrices keep it.
     int variant = g_sell_variant;
-    if (variant == 0 && a.lp_col && a.lp_base && sell_nt(a)) {   // 16-bit column offsets are available: 10 B per entry
-      hipLaunchKernelGGL((k_spmv_sell<4, true, unsigned short>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
-                         a.n, a.lp_col, a.sl_val, x, y, a.lp_base);
+    if ((variant == 0 || variant >= 5) && a.lp_col && a.lp_base && sell_nt(a)) {   // 16-bit column offsets are available: 10 B per entry
+      if (variant == 6)          // round-2 form: 4 steps in flight + one-at-a-time tail
+        hipLaunchKernelGGL((k_spmv_sell<4, true, unsigned short>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
+                           a.n, a.lp_col, a.sl_val, x, y, a.lp_base);
+      else if (variant == 7)     // predicated form without the non-temporal hint
+        hipLaunchKernelGGL((k_spmv_sell_p8<false, unsigned short>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
+                           a.n, a.lp_col, a.sl_val, x, y, a.lp_base);
+      else
+        hipLaunchKernelGGL((k_spmv_sell_p8<true, unsigned short>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
+                           a.n, a.lp_col, a.sl_val, x, y, a.lp_base);
       if (a.nlong > 0)
         hipLaunchKernelGGL(k_spmv_long, dim3(a.nlong), dim3(256), 0, g_stream, a.long_rows, a.rowptr, a.col, a.val, x, y);
       return;

@@ -6,7 +6,7 @@ reports half the bytes of a wide streaming read, WRITE_SIZE is exact.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d A -- python3 scripts/pmc.py work [n] [split]
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d B -- python3 scripts/pmc.py work [n] [split]
-    python3 scripts/pmc.py report A B work.json > profiles/r02_hbm_traffic_pmc.json        (scripts/gpu.sh pmc2 does all)
+    python3 scripts/pmc.py report A B work.json > profiles/r03_hbm_traffic_pmc.json        (scripts/gpu.sh pmc2 does all)
 
 `work` runs, on the bench workload's fine-level matrix (block-diagonal A_Dir of the 8 subdomains): the calibration
 kernel k_axpby on two 40 M-element vectors (reads 640 MB, writes 320 MB: also evicts the 256 MiB Infinity Cache between
@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"k_spmv_sell<": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96",
+KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96",
            "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32": "lobpcg_update32"}
 CALIB = 40_000_000
 
@@ -100,7 +100,9 @@ def report(fd, wd, alg_json):
     alg = json.load(open(alg_json))
     fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     mean = lambda v: sum(v) / len(v)
-    rep = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only; counters are "
+    import hashlib
+    rep = {"kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "geneo4petsc_amd", "csrc", "backend_hip.hip"), "rb").read()).hexdigest()[:16],
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only; counters are "
                      "in units of 1024 B; read bytes calibrated on k_axpby (16 B read + 8 B written per element, "
                      "%d elements) in the same pass" % alg["calib_elems"]}
     kax = [k for k in fetch if "k_axpby" in k]
