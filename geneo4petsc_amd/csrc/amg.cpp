@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <exception>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -625,6 +626,26 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     if (!ok) { bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
     bk::Csr Ac = bk::spgemm(R, AP, nc, &ok);
     if (!ok) { bk::csr_free(AP); bk::csr_free(P); bk::csr_free(R); bk::dfree(L.dinv); return abandon(); }
+    // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse.  The download runs on a
+    // helper thread with its own stream (ordered behind the product that made Ac) while this one finishes the level:
+    // SpMV layouts of P, R, Ac, the column-scaled copy and the post-smoothing matrix M.
+    HostCsr next;
+    next.n = nc;
+    next.rowptr.resize((size_t)nc + 1);
+    next.col.resize((size_t)Ac.nnz);
+    next.val.resize((size_t)Ac.nnz);
+    std::exception_ptr dl_err;
+    void* parent = bk::get_stream();
+    std::thread dl([&]() {
+      try {
+        bk::side_stream_begin(parent, true);
+        bk::csr_download(Ac, next.rowptr.data(), next.col.data(), next.val.data());
+      } catch (...) {
+        dl_err = std::current_exception();
+      }
+      bk::side_stream_end();
+    });
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } dl_join{dl};
     bk::csr_finish(P);
     bk::csr_finish(R);
     bk::csr_finish(Ac);
@@ -636,13 +657,8 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     make_column_scaled(L);
     make_post_matrix(L, &AP, nc);       // consumes A P
     lv.push_back(L);
-    // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse
-    HostCsr next;
-    next.n = nc;
-    next.rowptr.resize((size_t)nc + 1);
-    next.col.resize((size_t)Ac.nnz);
-    next.val.resize((size_t)Ac.nnz);
-    bk::csr_download(Ac, next.rowptr.data(), next.col.data(), next.val.data());
+    dl.join();
+    if (dl_err) std::rethrow_exception(dl_err);
     if (dbg)
       fprintf(stderr, "[amg/device] level n %d -> %d nnz %zu -> %zu | host diag+aggregation %.3f, device products %.3f, download %.3f s\n",
               n, nc, Ah.val.size(), next.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, tnow()));

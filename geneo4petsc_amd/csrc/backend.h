@@ -24,7 +24,9 @@ void sync();                              // wait for the calling thread's strea
 // everything queued on the main stream so far, end waits for it (results are then safe on any stream) and returns the
 // thread to the main stream.  Cached device blocks carry the stream of their last user, so blocks travel safely
 // between the two.  The level-1 hierarchy is built this way while the main stream runs the eigensolve.
-void side_stream_begin();
+// (after / use_after: order the private stream behind THAT stream instead of the main one -- a thread that itself runs
+//  on a side stream hands bk::get_stream() to the helper threads it starts)
+void side_stream_begin(void* after = nullptr, bool use_after = false);
 void side_stream_end();
 
 int   device_count();                     // GPUs visible to this process
@@ -102,7 +104,8 @@ void spmv(const Csr& a, const double* x, double* y);                    // y = A
 void spmv_profile_start(int every, double min_bytes);   // only launches moving >= min_bytes algorithmic bytes
 void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch);
 // all kernel classes at once: fine-level SpMV / SpMM (Csr::fine), MFMA Gram and block update (p, q >= 32)
-enum { PROF_SPMV = 0, PROF_SPMM = 1, PROF_GRAM = 2, PROF_BLOCKMUL = 3, PROF_NCLASS = 4 };
+// PROF_LP: the single-precision-companion passes of the local solves' V-cycle over the fine-level operators
+enum { PROF_SPMV = 0, PROF_SPMM = 1, PROF_GRAM = 2, PROF_BLOCKMUL = 3, PROF_LP = 4, PROF_NCLASS = 5 };
 void kernel_profile_start(int every, double spmv_min_bytes);
 void kernel_profile_stop();
 void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flops_sum, long long* nsampled, long long* nlaunch);

@@ -66,13 +66,14 @@ void set_stream(void* s) {
   if ((hipStream_t)s != g_stream_main) (void)hipStreamSynchronize(g_stream_main);
   g_stream_main = (hipStream_t)s;
 }
-void side_stream_begin() {
+void side_stream_begin(void* after, bool use_after) {
   if (t_side) return;
   if (!t_stream_side) HIPCHK(hipStreamCreateWithFlags(&t_stream_side, hipStreamNonBlocking));
-  // ordered behind everything the main stream has been given so far (the matrices this thread is going to read)
+  // ordered behind everything the parent stream (default: the main stream) has been given so far -- the matrices this
+  // thread is going to read
   hipEvent_t ev;
   HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ev, g_stream_main));
+  HIPCHK(hipEventRecord(ev, use_after ? (hipStream_t)after : g_stream_main));
   HIPCHK(hipStreamWaitEvent(t_stream_side, ev, 0));
   (void)hipEventDestroy(ev);
   t_side = true;
@@ -1216,6 +1217,110 @@ static void spmv_wide_launch(const Csr& a, const double* x, double* y, const dou
   hipLaunchKernelGGL((k_spmv_sell_wide<EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, a.sl_col,
                      a.sl_val, x, y, b, z, dinv, w, a.col_scaled ? (const double*)nullptr : dinv);
 }
+// In-situ kernel timing (bench.py): while profiling is on, every `every`-th launch of each kernel class is bracketed by
+// two HIP events on the launch stream; nothing waits on the host until stop.  Classes (backend.h): fine-level CSR
+// SpMV, fine-level SpMM, MFMA Gram, MFMA block update.
+struct KProf {
+  long long nlaunch = 0;     // direct launches seen (every `every`-th of them is timed)
+  long long ngraph = 0;      // launches replayed from HIP graphs (counted, never timed)
+  std::vector<hipEvent_t> e0, e1;
+  std::vector<double> bytes, flops;
+};
+static bool g_prof_on = false;
+static int g_prof_every = 1;
+static double g_prof_min_bytes = 0.0;
+static KProf g_kprof[PROF_NCLASS];
+static long long g_capture_count[PROF_NCLASS] = {0, 0, 0, 0, 0};
+struct GraphCounts { void* exec; long long n[PROF_NCLASS]; };
+static std::vector<GraphCounts> g_graph_counts;
+struct ProfScope {   // e0 at construction, e1 at destruction, when this launch is one of the sampled ones
+  KProf* k = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int cls, bool counted, double bytes, double flops) {
+    if (g_capturing && counted) ++g_capture_count[cls];    // what one replay of the graph being recorded will launch
+    if (!g_prof_on || g_capturing || !counted) return;
+    KProf& kp = g_kprof[cls];
+    if (kp.nlaunch++ % g_prof_every != 0 || kp.e0.size() >= 20000) return;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, g_stream));
+    k = &kp;
+    kp.bytes.push_back(bytes);
+    kp.flops.push_back(flops);
+  }
+  ~ProfScope() {
+    if (!k) return;
+    (void)hipEventRecord(b, g_stream);
+    k->e0.push_back(a);
+    k->e1.push_back(b);
+  }
+};
+static void kprof_clear(KProf& k) {
+  for (hipEvent_t e : k.e0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : k.e1) (void)hipEventDestroy(e);
+  k.e0.clear(); k.e1.clear(); k.bytes.clear(); k.flops.clear();
+  k.nlaunch = 0;
+  k.ngraph = 0;
+}
+static void graph_counts_reset() {
+  for (long long& v : g_capture_count) v = 0;
+}
+static void graph_counts_store(void* exec) {
+  GraphCounts gc;
+  gc.exec = exec;
+  for (int i = 0; i < PROF_NCLASS; ++i) gc.n[i] = g_capture_count[i];
+  g_graph_counts.push_back(gc);
+}
+static void graph_counts_add(void* exec) {
+  if (!g_prof_on) return;
+  for (const GraphCounts& gc : g_graph_counts)
+    if (gc.exec == exec) {
+      for (int i = 0; i < PROF_NCLASS; ++i) g_kprof[i].ngraph += gc.n[i];
+      return;
+    }
+}
+static void graph_counts_drop(void* exec) {
+  for (size_t i = 0; i < g_graph_counts.size(); ++i)
+    if (g_graph_counts[i].exec == exec) {
+      g_graph_counts.erase(g_graph_counts.begin() + i);
+      return;
+    }
+}
+void kernel_profile_start(int every, double spmv_min_bytes) {
+  for (KProf& k : g_kprof) kprof_clear(k);
+  g_prof_on = true;
+  g_prof_every = every < 1 ? 1 : every;
+  g_prof_min_bytes = spmv_min_bytes;
+}
+void kernel_profile_stop() {
+  g_prof_on = false;
+  HIPCHK(hipStreamSynchronize(g_stream));
+}
+void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flops_sum, long long* nsampled,
+                        long long* nlaunch) {
+  double ms = 0.0, by = 0.0, fl = 0.0;
+  if (cls < 0 || cls >= PROF_NCLASS) throw std::runtime_error("kernel_profile_get: unknown class");
+  KProf& k = g_kprof[cls];
+  for (size_t i = 0; i < k.e1.size(); ++i) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, k.e0[i], k.e1[i]));
+    ms += t;
+    by += k.bytes[i];
+    fl += k.flops[i];
+  }
+  if (ms_sum) *ms_sum = ms;
+  if (bytes_sum) *bytes_sum = by;
+  if (flops_sum) *flops_sum = fl;
+  if (nsampled) *nsampled = (long long)k.e1.size();
+  if (nlaunch) *nlaunch = k.nlaunch + k.ngraph;
+}
+void spmv_profile_start(int every, double min_bytes) { kernel_profile_start(every, min_bytes); }
+bool spmv_profiling() { return g_prof_on; }
+void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
+  kernel_profile_stop();
+  kernel_profile_get(PROF_SPMV, ms_sum, bytes_sum, nullptr, nsampled, nlaunch);
+}
+
 // ------------------------------------------------------------------------------- single-precision companion
 // (col, val) of the slices at 6 bytes per entry for the V-cycle of the local solves: the preconditioner of an FP64 PCG
 // needs its operator to a few digits only, and its passes over the fine and first coarse matrices are pure HBM streams.
@@ -1356,6 +1461,13 @@ template <int EPI>
 static void spmv_lp_launch(const Csr& a, const double* x, double* y, const double* b, double* z, const double* dinv, double w) {
   if (!a.lp_val) throw std::runtime_error("spmv_lp: the matrix has no single-precision companion");
   if (a.n == 0) return;
+  // in-situ timer class PROF_LP: the V-cycle's passes over the LARGE operators (fine level: A diag(dinv), M, R; >= 32 MB
+  // of companion entries).  Algorithmic bytes: 6 per stored entry (float value + 16-bit column; 8 when the slice spans
+  // more than 65535 columns) + 4 per slice + 8 per row and vector the epilogue streams (x or b in, y out, plus z / r).
+  constexpr int nvec = EPI == EPI_NONE ? 2 : (EPI == EPI_POST ? 5 : (EPI == EPI_JAC ? 4 : 3));
+  const double ebytes = a.lp_col ? 6.0 : 8.0;
+  ProfScope prof(PROF_LP, (double)a.sl_nnz * ebytes >= 32e6, (double)a.sl_nnz * ebytes + 4.0 * a.nslice + 8.0 * nvec * (double)a.n,
+                 2.0 * (double)a.nnz);
   const double* cs = (EPI == EPI_PRE && !a.col_scaled) ? dinv : nullptr;
   const int per = (a.nslice + 7) / 8;
   const int perw = ((a.nslice + 3) / 4 + 7) / 8;
@@ -1461,110 +1573,6 @@ void set_spmv_kind(int kind) {     // kind = layout + 10 * variant + 100 * (1: r
   g_spmv_kind = (kind % 10) ? 1 : 0;
   g_sell_variant = (kind / 10) % 10;
   g_force_slices = (kind / 100) % 10 == 1;
-}
-
-// In-situ kernel timing (bench.py): while profiling is on, every `every`-th launch of each kernel class is bracketed by
-// two HIP events on the launch stream; nothing waits on the host until stop.  Classes (backend.h): fine-level CSR
-// SpMV, fine-level SpMM, MFMA Gram, MFMA block update.
-struct KProf {
-  long long nlaunch = 0;     // direct launches seen (every `every`-th of them is timed)
-  long long ngraph = 0;      // launches replayed from HIP graphs (counted, never timed)
-  std::vector<hipEvent_t> e0, e1;
-  std::vector<double> bytes, flops;
-};
-static bool g_prof_on = false;
-static int g_prof_every = 1;
-static double g_prof_min_bytes = 0.0;
-static KProf g_kprof[PROF_NCLASS];
-static long long g_capture_count[PROF_NCLASS] = {0, 0, 0, 0};
-struct GraphCounts { void* exec; long long n[PROF_NCLASS]; };
-static std::vector<GraphCounts> g_graph_counts;
-struct ProfScope {   // e0 at construction, e1 at destruction, when this launch is one of the sampled ones
-  KProf* k = nullptr;
-  hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(int cls, bool counted, double bytes, double flops) {
-    if (g_capturing && counted) ++g_capture_count[cls];    // what one replay of the graph being recorded will launch
-    if (!g_prof_on || g_capturing || !counted) return;
-    KProf& kp = g_kprof[cls];
-    if (kp.nlaunch++ % g_prof_every != 0 || kp.e0.size() >= 20000) return;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipEventRecord(a, g_stream));
-    k = &kp;
-    kp.bytes.push_back(bytes);
-    kp.flops.push_back(flops);
-  }
-  ~ProfScope() {
-    if (!k) return;
-    (void)hipEventRecord(b, g_stream);
-    k->e0.push_back(a);
-    k->e1.push_back(b);
-  }
-};
-static void kprof_clear(KProf& k) {
-  for (hipEvent_t e : k.e0) (void)hipEventDestroy(e);
-  for (hipEvent_t e : k.e1) (void)hipEventDestroy(e);
-  k.e0.clear(); k.e1.clear(); k.bytes.clear(); k.flops.clear();
-  k.nlaunch = 0;
-  k.ngraph = 0;
-}
-static void graph_counts_reset() {
-  for (long long& v : g_capture_count) v = 0;
-}
-static void graph_counts_store(void* exec) {
-  GraphCounts gc;
-  gc.exec = exec;
-  for (int i = 0; i < PROF_NCLASS; ++i) gc.n[i] = g_capture_count[i];
-  g_graph_counts.push_back(gc);
-}
-static void graph_counts_add(void* exec) {
-  if (!g_prof_on) return;
-  for (const GraphCounts& gc : g_graph_counts)
-    if (gc.exec == exec) {
-      for (int i = 0; i < PROF_NCLASS; ++i) g_kprof[i].ngraph += gc.n[i];
-      return;
-    }
-}
-static void graph_counts_drop(void* exec) {
-  for (size_t i = 0; i < g_graph_counts.size(); ++i)
-    if (g_graph_counts[i].exec == exec) {
-      g_graph_counts.erase(g_graph_counts.begin() + i);
-      return;
-    }
-}
-void kernel_profile_start(int every, double spmv_min_bytes) {
-  for (KProf& k : g_kprof) kprof_clear(k);
-  g_prof_on = true;
-  g_prof_every = every < 1 ? 1 : every;
-  g_prof_min_bytes = spmv_min_bytes;
-}
-void kernel_profile_stop() {
-  g_prof_on = false;
-  HIPCHK(hipStreamSynchronize(g_stream));
-}
-void kernel_profile_get(int cls, double* ms_sum, double* bytes_sum, double* flops_sum, long long* nsampled,
-                        long long* nlaunch) {
-  double ms = 0.0, by = 0.0, fl = 0.0;
-  if (cls < 0 || cls >= PROF_NCLASS) throw std::runtime_error("kernel_profile_get: unknown class");
-  KProf& k = g_kprof[cls];
-  for (size_t i = 0; i < k.e1.size(); ++i) {
-    float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, k.e0[i], k.e1[i]));
-    ms += t;
-    by += k.bytes[i];
-    fl += k.flops[i];
-  }
-  if (ms_sum) *ms_sum = ms;
-  if (bytes_sum) *bytes_sum = by;
-  if (flops_sum) *flops_sum = fl;
-  if (nsampled) *nsampled = (long long)k.e1.size();
-  if (nlaunch) *nlaunch = k.nlaunch + k.ngraph;
-}
-void spmv_profile_start(int every, double min_bytes) { kernel_profile_start(every, min_bytes); }
-bool spmv_profiling() { return g_prof_on; }
-void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
-  kernel_profile_stop();
-  kernel_profile_get(PROF_SPMV, ms_sum, bytes_sum, nullptr, nsampled, nlaunch);
 }
 
 void spmv(const Csr& a, const double* x, double* y) {

@@ -195,8 +195,9 @@ struct AmgHostResult {
 struct PC::Amg1Pending {
   HostCsr mat;
   AmgHostResult res;
-  AmgDevice* dev = nullptr;     // uploaded by the same thread on its side stream (handed to PC::amg1 at the join)
+  AmgDevice* dev = nullptr;     // built / uploaded by the same thread on its side stream (handed to PC::amg1 at the join)
   double upload_secs = 0.0;
+  bool on_device = false;       // sparse products on the device (host: aggregation only)
   std::thread th;
   ~Amg1Pending() {
     if (th.joinable()) th.join();
@@ -572,8 +573,9 @@ int PC::finish_amg1() {
   info.amgSetupTime += tot;
   info.lvl1SetupMinvTimeLoc += tot;
   if (getenv("GENEO_DEBUG"))
-    fprintf(stderr, "[amg] level-1 hierarchy on its own thread: host set-up %.3f s, upload on the side stream %.3f s; waited %.3f s for it\n",
-            p->res.secs, p->upload_secs, waited);
+    fprintf(stderr, "[amg] level-1 hierarchy on its own thread and stream (%s): %.3f s%s; waited %.3f s for it\n",
+            p->on_device ? "device products, host aggregation" : "host products", p->res.secs,
+            p->on_device ? "" : (" + upload " + std::to_string(p->upload_secs) + " s").c_str(), waited);
   return 0;
 }
 
@@ -738,16 +740,25 @@ int PC::setup(const double* b_dev) {
       pp->th = std::thread([pp, so, ap, max_m1, fine]() {
         auto t0 = clk::now();
         try {
-          amg_setup_host(pp->mat, so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
-          pp->res.secs = secs(t0, clk::now());
-          // upload + device-side products (R = P^T, M = P - w D^-1 A P, companions) on a private stream, concurrently
-          // with whatever the main stream is running (the eigensolve)
-          auto t1 = clk::now();
+          // Everything this thread launches goes to a private stream, concurrently with whatever the main stream is
+          // running (the eigensolve).  Default: the sparse products of the hierarchy on the device (the host only
+          // aggregates), as for the A_Neu hierarchy -- with ONE subdomain per GPU the host products of a 6.4 M-row matrix
+          // took 1.07 s and were the critical path of the set-up.  GENEO_AMG1_HOST=1 (or a row beyond the product
+          // kernels' capacity): host products + upload.
           bk::side_stream_begin();
           pp->dev = new AmgDevice();
-          pp->dev->upload(pp->res.levels, pp->res.cinv, pp->res.cbase, ap, max_m1, fine);
+          bool built = false;
+          if (!getenv("GENEO_AMG1_HOST") && !getenv("GENEO_AMG_HOST")) built = pp->dev->build_on_device(pp->mat, so, ap, max_m1, fine);
+          pp->res.secs = secs(t0, clk::now());
+          pp->on_device = built;
+          if (!built) {
+            amg_setup_host(pp->mat, so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
+            pp->res.secs = secs(t0, clk::now());
+            auto t1 = clk::now();
+            pp->dev->upload(pp->res.levels, pp->res.cinv, pp->res.cbase, ap, max_m1, fine);
+            pp->upload_secs = secs(t1, clk::now());
+          }
           bk::side_stream_end();
-          pp->upload_secs = secs(t1, clk::now());
         } catch (std::exception& e) {
           bk::side_stream_end();
           pp->res.err = e.what();

@@ -24,7 +24,7 @@ void* get_stream() { return g_stream; }
 void sync() {}
 int device_count() { return 0; }
 int set_device(int) { return -1; }
-void side_stream_begin() {}
+void side_stream_begin(void*, bool) {}
 void side_stream_end() {}
 
 void* alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
