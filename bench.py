@@ -130,7 +130,7 @@ def build_problem(args, rank, size):
     n, parts, sub_rank, spg = workload(args, size)
     nb = len(sub_rank)
     my = [s for s in range(nb) if sub_rank[s] == rank]
-    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s) for s in my]
+    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True) for s in my]
     plan = decomp.grid_rank_plan(n, 3, parts, args.overlap, sub_rank, rank, size, doms)
     # b = A (1, 2, ..., N) (driver:820-831) on the owned rows
     npart_of = lambda gid: ((gid % n) * parts[0]) // n + parts[0] * ((((gid // n) % n) * parts[1]) // n
@@ -157,7 +157,7 @@ def build_problem_unstructured(args):
         n = args.n if args.n else (args.n_per_gpu or 126)
         gen = dict(heat=True, lbd=1.0, dt=0.1, kappa_max=args.kappa, interp="minmax")
         parts = (2, 2, 2)
-        doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, **gen) for s in range(8)]
+        doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True, **gen) for s in range(8)]
         ndof = n ** 3
         # b = A (1..N) from the Dirichlet rows of the domain that owns each node (driver:820-831)
         npart = decomp.structured_node_partition(n, 3, parts)
@@ -174,7 +174,7 @@ def build_problem_unstructured(args):
     t1 = time.perf_counter()
     ep, npart, cut = decomp.partition_mesh_native(mesh, 8, False)
     t2 = time.perf_counter()
-    dec = decomp.decompose(mesh, 8, None, npart, False, args.overlap)
+    domains = decomp.decompose_native(mesh, 8, None, npart, False, args.overlap)
     t3 = time.perf_counter()
     a = decomp.global_matrix(mesh)
     b = decomp.rhs_default(a)
@@ -184,7 +184,7 @@ def build_problem_unstructured(args):
              "part_sizes": [int(c) for c in counts], "global_nnz": int(a.nnz)}
     desc = ("tst/graph generator (reference graph.cpp: --size %d --level 2 --noGround), %d nodes, nodal k-way partition into 8 "
             "(edge cut %d), overlap %d: irregular CSR" % (args.graph_size, mesh.nbNode, cut, args.overlap))
-    return desc, mesh.nbNode, 8, dec.domains, _WholePlan(mesh.nbNode), b, facts
+    return desc, mesh.nbNode, 8, domains, _WholePlan(mesh.nbNode), b, facts
 
 
 def cpu_baseline(args, doms, lib):
@@ -280,7 +280,7 @@ def one_rank_of(args):
     n = args.n if args.n else 2 * npg
     parts = (2, 2, 2)
     t_prep = time.perf_counter()
-    dom = decomp.decompose_grid_domain(n, 3, parts, args.overlap, args.rank_index)
+    dom = decomp.decompose_grid_domain(n, 3, parts, args.overlap, args.rank_index, native=True)
     nloc = len(dom.l2g)
     b = dom.a_neu @ (np.arange(nloc, dtype=np.float64) + 1.0)
     prep_s = time.perf_counter() - t_prep
@@ -372,7 +372,7 @@ def one_gpu_anchor(args, lib, torch):
     n = args.n_per_gpu or 184
     parts = (2, 2, 2)
     t0 = time.perf_counter()
-    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s) for s in range(8)]
+    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True) for s in range(8)]
     npart = decomp.structured_node_partition(n, 3, parts)
     b = np.zeros(n ** 3)
     for d in doms:

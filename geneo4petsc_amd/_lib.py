@@ -38,6 +38,14 @@ class GeneoInfo(C.Structure):
                 ("nullPivotsLoc", C.c_int)]
 
 
+class GeneoDomain(C.Structure):
+    """include/geneo_c.h GeneoDomain: one domain of GeneoDecompDomain (arrays owned by the library: GeneoFreeDomain)"""
+    _fields_ = [("n", C.c_int), ("l2g", c_int_p), ("mult", c_int_p),
+                ("neu_rowptr", c_int_p), ("neu_col", c_int_p), ("neu_val", c_dbl_p),
+                ("dir_rowptr", c_int_p), ("dir_col", c_int_p), ("dir_val", c_dbl_p),
+                ("inter_ptr", c_int_p), ("inter_idx", c_int_p)]
+
+
 class GeneoInput(C.Structure):
     _fields_ = [("nbElem", C.c_uint), ("nbNode", C.c_uint), ("elemPtr", C.POINTER(C.c_uint)),
                 ("elemIdx", C.POINTER(C.c_uint)), ("elemMat", c_dbl_p), ("nIdx", C.c_size_t), ("nMat", C.c_size_t)]
@@ -100,6 +108,14 @@ SYMBOLS = {
                                C.c_longlong]),
     "GeneoBackendName": (C.c_char_p, []),
     "GeneoSetStream": (C.c_int, [C.c_void_p]),
+    "GeneoDecompCreate": (C.c_int, [C.c_int, C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_int_p, c_int_p, C.c_int, C.c_int,
+                                    C.POINTER(C.c_void_p)]),
+    "GeneoDecompDomain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(GeneoDomain)]),
+    "GeneoFreeDomain": (None, [C.POINTER(GeneoDomain)]),
+    "GeneoDecompDestroy": (None, [C.POINTER(C.c_void_p)]),
+    "GeneoGridMesh": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, c_int_p, c_int_p,
+                                c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_dbl_p)]),
+    "GeneoFreeMesh": (None, [c_int_p, c_dbl_p]),
     "GeneoPartMeshDual": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "GeneoPartMeshNodal": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "GeneoPartGraphKway": (C.c_int, [C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]),

@@ -957,7 +957,7 @@ def _l1_dist_to_box(coords, lo, hi):
     return dist
 
 
-def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, **gen) -> Domain:
+def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, native=False, **gen) -> Domain:
     """Domain p of a structured nodal decomposition WITHOUT touching the whole grid: everything that
     determines domain p (its elements, the multiplicity of its nodes and elements, the assembled rows
     of its nodes) lives inside box_p grown by 2*overlap+3 nodes, so the generic element-based
@@ -969,7 +969,7 @@ def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, **
     g = 2 * overlap + 3
     wlo = tuple(max(0, lo[a] - g) if a < dim else 0 for a in range(3))
     whi = tuple(min(d[a], hi[a] + g) if a < dim else 1 for a in range(3))
-    mesh = grid_mesh(n=n, dim=dim, window=(wlo, whi), **gen)
+    mesh = (grid_mesh_native if native else grid_mesh)(n=n, dim=dim, window=(wlo, whi), **gen)
     # window-local renumbering
     wi = np.arange(wlo[0], whi[0])[None, None, :]
     wj = np.arange(wlo[1], whi[1])[None, :, None]
@@ -987,9 +987,11 @@ def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, **
     ids = np.unique(part)
     remap = {int(q): t for t, q in enumerate(ids)}
     npart = np.searchsorted(ids, part)
-    dec = decompose(wmesh, len(ids), None, npart, False, overlap, build=True, with_dirichlet=with_dirichlet,
-                    parts=[remap[p]])
-    dom = dec.domains[0]
+    if native:
+        dom = decompose_native(wmesh, len(ids), None, npart, False, overlap, with_dirichlet=with_dirichlet, parts=[remap[p]])[0]
+    else:
+        dom = decompose(wmesh, len(ids), None, npart, False, overlap, build=True, with_dirichlet=with_dirichlet,
+                        parts=[remap[p]]).domains[0]
     dom.gid = p
     dom.l2g = gids[dom.l2g]
     inter = [np.zeros(0, dtype=np.int64) for _ in range(len(boxes))]
@@ -997,6 +999,83 @@ def decompose_grid_domain(n, dim, parts_xyz, overlap, p, with_dirichlet=True, **
         inter[q] = dom.intersect[t]
     dom.intersect = inter
     return dom
+
+
+# ------------------------------------------------------------------------------- native (C++) host path
+_INTERP = {"": 0, "quad": 1, "lin": 2, "minmax": 3}
+
+
+def grid_mesh_native(size=4, weak=1, dim=3, inp_eps=1e-4, kappa_max=1.0, interp="", heat=False, lbd=1.0, dt=0.1,
+                     n: Optional[int] = None, window=None, lib=None) -> ElementMesh:
+    """grid_mesh through the library's C++ generator (csrc/decompose.cpp, GeneoGridMesh): same elements, same order, same
+    values to the bit (tests/test_decomp.py::test_native_generator_and_decomposition_equal_the_prototypes)."""
+    import ctypes as C
+    lib = lib if lib is not None else _host_lib()
+    if n is None:
+        n = grid_size(size, weak, dim)
+    ip = C.POINTER(C.c_int)
+    lo = hi = None
+    if window is not None:
+        lo = (C.c_int * 3)(*[int(v) for v in window[0]])
+        hi = (C.c_int * 3)(*[int(v) for v in window[1]])
+    nn, ne = C.c_int(0), C.c_int(0)
+    pn, pm = ip(), C.POINTER(C.c_double)()
+    if lib.GeneoGridMesh(int(n), int(dim), float(inp_eps), float(kappa_max), _INTERP[interp], 1 if heat else 0, float(lbd), float(dt),
+                         lo, hi, C.byref(nn), C.byref(ne), C.byref(pn), C.byref(pm)):
+        raise RuntimeError("GeneoGridMesh failed")
+    try:
+        nodes = np.ctypeslib.as_array(pn, shape=(max(1, ne.value), 2))[:ne.value].astype(np.int64)
+        mats = np.ctypeslib.as_array(pm, shape=(max(1, ne.value), 4))[:ne.value].copy()
+    finally:
+        lib.GeneoFreeMesh(pn, pm)
+    return ElementMesh(int(nn.value), nodes, mats)
+
+
+def decompose_native(mesh: ElementMesh, nb_part: int, elem_part=None, node_part=None, metis_dual=False, add_overlap=0,
+                     with_dirichlet=True, parts=None, lib=None) -> List[Domain]:
+    """decompose(...).domains through the library's C++ decomposition (csrc/decompose.cpp: GeneoDecompCreate /
+    GeneoDecompDomain, the counterpart of driver:196-379, :447-494, :643-715).  Same lists and patterns; matrix values
+    equal to a rounding error of the summation order."""
+    import ctypes as C
+    lib = lib if lib is not None else _host_lib()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    nodes = np.ascontiguousarray(mesh.nodes, dtype=np.int32)
+    mats = np.ascontiguousarray(mesh.mats, dtype=np.float64)
+    part = np.ascontiguousarray(elem_part if metis_dual else node_part, dtype=np.int32)
+    h = C.c_void_p()
+    if lib.GeneoDecompCreate(int(mesh.nbNode), int(mesh.nbElem), int(mesh.W), nodes.ctypes.data_as(ip), mats.ctypes.data_as(dp),
+                             int(nb_part), part.ctypes.data_as(ip) if metis_dual else None,
+                             None if metis_dual else part.ctypes.data_as(ip), 1 if metis_dual else 0, int(add_overlap), C.byref(h)):
+        raise RuntimeError("GeneoDecompCreate failed")
+    from . import _lib
+    out = []
+    try:
+        for p in (range(nb_part) if parts is None else parts):
+            dm = _lib.GeneoDomain()
+            if lib.GeneoDecompDomain(h, int(p), 1 if with_dirichlet else 0, C.byref(dm)):
+                raise RuntimeError("GeneoDecompDomain failed")
+            try:
+                n = dm.n
+                arr = lambda ptr, k, dt: np.ctypeslib.as_array(ptr, shape=(max(1, k),))[:k].astype(dt)
+                l2g = arr(dm.l2g, n, np.int64)
+                mult = arr(dm.mult, n, np.int64)
+
+                def csr(rp, col, val):
+                    rpa = arr(rp, n + 1, np.int32)
+                    nz = int(rpa[-1]) if n >= 0 else 0
+                    return sp.csr_matrix((arr(val, nz, np.float64), arr(col, nz, np.int32), rpa), shape=(n, n))
+
+                a_neu = csr(dm.neu_rowptr, dm.neu_col, dm.neu_val)
+                a_dir = csr(dm.dir_rowptr, dm.dir_col, dm.dir_val) if with_dirichlet else None
+                iptr = arr(dm.inter_ptr, nb_part + 1, np.int64)
+                iidx = arr(dm.inter_idx, int(iptr[-1]), np.int64)
+                inter = [iidx[iptr[q]:iptr[q + 1]] for q in range(nb_part)]
+                out.append(Domain(int(p), l2g, mult, a_neu, a_dir, inter))
+            finally:
+                lib.GeneoFreeDomain(C.byref(dm))
+    finally:
+        lib.GeneoDecompDestroy(C.byref(h))
+    return out
 
 
 def grid_rank_plan(n, dim, parts_xyz, overlap, sub_rank, rank, size, my_domains) -> RankPlan:

@@ -216,6 +216,33 @@ typedef struct {
 PetscErrorCode GeneoGetLibInput(const char* inpLibA, const char* inpLibArg, GeneoInput* out);
 void GeneoFreeInput(GeneoInput* in);
 
+/* ---- host-side decomposition and structured generators (csrc/decompose.cpp) ---------------------------------------
+ * The reference DRIVER's decompose + addOverlapLayers + buildDomain + fillALoc (src/geneo4PETSc.cpp:196-379, :447-494,
+ * :643-715): from the element lists and a k-way partition (elemPart when dual, nodePart when nodal) to each domain's
+ * ascending global node list, multiplicities, MATIS local matrix A_Neu (element matrices weighted 1 / elemMult) and
+ * A_Dir = R A R^T, plus the lists of local indices shared with every other domain (intersectLoc, hdr/geneo.hpp:34).
+ * nodes: nbElem x W node ids (-1: unused slot), mats: nbElem x W*W; both must outlive the handle.  GeneoDomain arrays
+ * are malloc'ed by the library: release with GeneoFreeDomain.  Host code only. */
+typedef struct _p_GeneoDecomp* GeneoDecomp;
+typedef struct {
+  int n;                                /* local DOFs */
+  int *l2g, *mult;                      /* n each */
+  int *neu_rowptr, *neu_col; double* neu_val;
+  int *dir_rowptr, *dir_col; double* dir_val;     /* NULL without withDirichlet */
+  int *inter_ptr, *inter_idx;           /* nbPart + 1 offsets into the shared local indices, per other part */
+} GeneoDomain;
+PetscErrorCode GeneoDecompCreate(int nbNode, int nbElem, int W, const int* nodes, const double* mats, int nbPart,
+                                 const int* elemPart, const int* nodePart, int dual, int addOverlap, GeneoDecomp* out);
+PetscErrorCode GeneoDecompDomain(GeneoDecomp d, int p, int withDirichlet, GeneoDomain* out);
+void GeneoFreeDomain(GeneoDomain* dom);
+void GeneoDecompDestroy(GeneoDecomp* d);
+/* tst/laplacian (laplacian.cpp:57-188) / tst/heat (heat.cpp:64-261) generator on an n^dim grid (interp: 0 none, 1 quad,
+ * 2 lin, 3 minmax), optionally restricted to the elements inside the node-index box [wlo, whi) (NULL: whole grid).
+ * nodes (nbElem x 2, -1 in the second slot of a Dirichlet element) and mats (nbElem x 4) are malloc'ed: GeneoFreeMesh. */
+PetscErrorCode GeneoGridMesh(int n, int dim, double inpEps, double kappaMax, int interp, int heat, double lbd, double dt,
+                             const int* wlo, const int* whi, int* nbNode, int* nbElem, int** nodes, double** mats);
+void GeneoFreeMesh(int* nodes, double* mats);
+
 /* ---- host k-way mesh partitioner (csrc/partition.cpp): what the reference's driver asks of Metis 5.1.0 --------------
  * METIS_PartMeshDual(&ne, &nn, eptr, eind, NULL, NULL, &ncommon = 1, &nparts, NULL, options, &objval, epart, npart) and
  * METIS_PartMeshNodal(&ne, &nn, eptr, eind, NULL, NULL, &nparts, NULL, options, &objval, epart, npart) with

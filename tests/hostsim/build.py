@@ -15,7 +15,7 @@ OUT = os.path.join(HERE, "libgeneopc_hostsim.so")
 
 def build(force=False):
     srcs = [os.path.join(CSRC, "core.cpp"), os.path.join(CSRC, "amg.cpp"), os.path.join(CSRC, "capi.cpp"),
-            os.path.join(CSRC, "comm_rccl.cpp"), os.path.join(CSRC, "partition.cpp"),
+            os.path.join(CSRC, "comm_rccl.cpp"), os.path.join(CSRC, "partition.cpp"), os.path.join(CSRC, "decompose.cpp"),
             os.path.join(HERE, "backend_host.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("core.h", "backend.h", "dense.h", "amg.h")] + \
         [os.path.join(ROOT, "include", "geneo_c.h")]

@@ -187,3 +187,32 @@ def test_native_partitioner_irregular_graph_and_csr_entry():
     assert (decomp.partition_graph_native(g, 1) == 0).all()
     with pytest.raises(RuntimeError):
         decomp.partition_graph_native(g, g.shape[0] + 1)
+
+
+def test_native_generator_and_decomposition_equal_the_prototypes():
+    """csrc/decompose.cpp (GeneoGridMesh, GeneoDecompCreate / GeneoDecompDomain: the C++ counterparts of the reference's
+    generators and of driver:196-379, :447-494, :643-715, used by bench.py) against the numpy prototypes the parity tests
+    read: generator output identical to the bit (elements, order, values: laplacian / heat, every interpolation, 1-D to
+    3-D, windowed); decomposition lists identical, matrix patterns identical, values to a rounding error of the summation
+    order; the windowed one-domain path too."""
+    for kw in (dict(n=9, dim=3), dict(n=12, dim=2, kappa_max=3.0, interp="lin"), dict(n=8, dim=1),
+               dict(n=7, dim=3, heat=True, kappa_max=100.0, interp="minmax"),
+               dict(n=9, dim=3, kappa_max=2.0, interp="quad", window=((1, 0, 2), (7, 9, 8)))):
+        a, b = decomp.grid_mesh(**kw), decomp.grid_mesh_native(**kw)
+        assert a.nbNode == b.nbNode and np.array_equal(a.nodes, b.nodes) and np.array_equal(a.mats, b.mats), kw
+    mesh = decomp.grid_mesh(n=10, dim=3, kappa_max=2.0, interp="lin")
+    for dual in (False, True):
+        ep, npt = decomp.partition_mesh(mesh, 5, dual)
+        for ov in (0, 2):
+            ref = decomp.decompose(mesh, 5, ep, npt, dual, ov).domains
+            nat = decomp.decompose_native(mesh, 5, ep, npt, dual, ov)
+            for r, t in zip(ref, nat):
+                assert np.array_equal(r.l2g, t.l2g) and np.array_equal(r.mult, t.mult)
+                for x, y in ((r.a_neu, t.a_neu), (r.a_dir, t.a_dir)):
+                    assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices)
+                    assert np.abs(x.data - y.data).max() <= 4e-16 * np.abs(x.data).max()
+                assert all(np.array_equal(i, j) for i, j in zip(r.intersect, t.intersect))
+    d1 = decomp.decompose_grid_domain(20, 3, (2, 2, 2), 2, 5)
+    d2 = decomp.decompose_grid_domain(20, 3, (2, 2, 2), 2, 5, native=True)
+    assert np.array_equal(d1.l2g, d2.l2g) and np.array_equal(d1.mult, d2.mult) and abs(d1.a_neu - d2.a_neu).max() < 1e-15
+    assert abs(d1.a_dir - d2.a_dir).max() < 1e-15 and all(np.array_equal(i, j) for i, j in zip(d1.intersect, d2.intersect))
