@@ -1602,7 +1602,10 @@ void spmv(const Csr& a, const double* x, double* y) {
     // access pattern) prefer the cached stream, which is why small (coarse-level) matrices keep it.
     int variant = g_sell_variant;
     if ((variant == 0 || variant >= 5) && a.lp_col && a.lp_base && sell_nt(a)) {   // 16-bit column offsets are available: 10 B per entry
-      if (variant == 6)          // round-2 form: 4 steps in flight + one-at-a-time tail
+      // Default: 4 steps in flight + one-at-a-time tail (the same accumulation order as the 32-bit-column kernel: the two
+      // paths agree to the bit).  GENEO_SELL_VARIANT=5 / 7: the predicated eight-step form (round-3 experiment: 20 % faster
+      // back to back on an evicted cache, no difference in situ -- 5037 vs 5017 GB/s -- and a different rounding).
+      if (variant == 0 || variant == 6)
         hipLaunchKernelGGL((k_spmv_sell<4, true, unsigned short>), dim3(perw * 8), dim3(256), 0, g_stream, a.sl_ptr, a.nslice,
                            a.n, a.lp_col, a.sl_val, x, y, a.lp_base);
       else if (variant == 7)     // predicated form without the non-temporal hint

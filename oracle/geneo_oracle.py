@@ -174,6 +174,17 @@ def _inertia_negative_count(m: sp.csr_matrix) -> tuple:
     return int(np.sum(d < 0)), int(np.sum(d == 0)), int(np.sum(d > 0))
 
 
+_FORK_ORACLE = None
+
+
+def _fork_coarse_worker(p):
+    """worker of GenEOOracle._build_coarse_space (forked: the oracle is inherited, only results travel back)"""
+    orc = _FORK_ORACLE
+    nic0, est0 = orc.nicolaidesLoc[p], orc.estimDimELoc[p]
+    vals, vecs = orc._coarse_for_subdomain(p)
+    return vals, vecs, orc.nicolaidesLoc[p] - nic0, orc.candidates[p], orc.tauLoc[p], orc.gammaLoc[p], orc.estimDimELoc[p] - est0
+
+
 class GenEOOracle:
     """All ranks of the reference in one process: subs[p] is what rank p would hold."""
 
@@ -395,25 +406,49 @@ class GenEOOracle:
         self.gammaLoc[p] = g
         return g
 
+    def _coarse_for_subdomain(self, p):
+        """the eigenproblems of subdomain p (buildCoarseSpaceWithGenEO, geneo.cpp:1243-1300): (eigenvalues, vectors) kept"""
+        o = self.o
+        s = self.subs[p]
+        dm = sp.diags(self.D[p])
+        b = (dm @ self.a_dir[p] @ dm).tocsr()                # :1243-1247
+        vals, vecs = [], []
+        if o.lvl2 == 1:
+            self._eigen_local_problem(p, s.a_neu, b, o.tau, "tau", vals, vecs)
+        else:
+            t = self._local_tau(p)
+            self._eigen_local_problem(p, s.a_neu, self.a_rob[p], t, "tau", vals, vecs)
+            g = self._local_gamma(p)
+            self._eigen_local_problem(p, b, self.a_rob[p], g, "gamma", vals, vecs)
+        return vals, vecs
+
     def _build_coarse_space(self):
         """buildCoarseSpaceWithGenEO, geneo.cpp:1234-1366."""
         o = self.o
         cut_saved = o.cut
+        if o.lvl2 == 2 and o.cut >= 2:                       # :1275 (each rank halves its own copy)
+            o.cut = o.cut // 2
         zcols = []      # list of (p, local vector D*v)
+        # self.workers > 1: the subdomains' eigenproblems on forked worker processes (they are independent: one per MPI
+        # rank in the reference) -- only used by bench.py's cpu_baseline leg, which states the core count it used
+        results = None
+        if getattr(self, "workers", 1) > 1 and self.P > 1:
+            import multiprocessing as mp
+            global _FORK_ORACLE
+            _FORK_ORACLE = self
+            with mp.get_context("fork").Pool(min(self.workers, self.P)) as pool:
+                results = pool.map(_fork_coarse_worker, range(self.P))
+            _FORK_ORACLE = None
         for p, s in enumerate(self.subs):
             d = self.D[p]
-            dm = sp.diags(d)
-            b = (dm @ self.a_dir[p] @ dm).tocsr()            # :1243-1247
-            vals, vecs = [], []
-            if o.lvl2 == 1:
-                self._eigen_local_problem(p, s.a_neu, b, o.tau, "tau", vals, vecs)
+            if results is not None:
+                vals, vecs, nic, cand, tl, gl, est = results[p]
+                self.nicolaidesLoc[p] += nic
+                self.estimDimELoc[p] += est
+                self.candidates[p] = cand
+                self.tauLoc[p], self.gammaLoc[p] = tl, gl
             else:
-                if p == 0 and o.cut >= 2:                    # :1275 (each rank halves its own copy)
-                    o.cut = o.cut // 2
-                t = self._local_tau(p)
-                self._eigen_local_problem(p, s.a_neu, self.a_rob[p], t, "tau", vals, vecs)
-                g = self._local_gamma(p)
-                self._eigen_local_problem(p, b, self.a_rob[p], g, "gamma", vals, vecs)
+                vals, vecs = self._coarse_for_subdomain(p)
             if len(vecs) == 0:                               # :1305-1314
                 vals.append(0.0)
                 vecs.append(np.ones(len(s.l2g)))

@@ -89,14 +89,31 @@ def test_variable_kappa_and_uneven_parts(lib):
 
 
 def test_heat_high_contrast(lib):
-    """BASELINE config 4: GenEO coarse space vs plain ASM on the anisotropic/high-contrast heat operator."""
+    """BASELINE config 4: GenEO coarse space vs plain ASM on the high-contrast heat operator (kappa = 100 on the middle
+    third of every axis: contrast 100^3 = 1e6).
+
+    Rounds 1-2 compared the coarse action here to 1e-7 "because E inherits the conditioning of A".  It does not:
+    cond(E) is ~2e2 (asserted below) and the dense E-solve is exact to 1e-15.  What limits the comparison is the
+    contrast itself: eigenvectors are normalised and converged in the B-inner product (B = D A_Dir D carries the
+    coefficient), so their components in the kappa = 1 regions weigh 1e-6 of those in the kappa = 1e6 region and are
+    resolved to eps * contrast = 2e-10 relative to the vector -- and Q b is compared in the 2-norm, which weighs all
+    components alike.  Any solver working in that inner product (ARPACK's shift-invert too) has this floor.  The bar is
+    therefore 100 eps contrast = 2.2e-8 for the operator actions of the two-level case, asserted together with
+    cond(E); the one-level case keeps the suite's 1e-9."""
+    contrast = 100.0 ** 3
     gen = dict(heat=True, kappa_max=100.0, interp="minmax")
     a0 = ["-geneo_lvl", "ASM,0", "-ksp_type", "cg"] + TIGHT
     a1 = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.015", "-geneo_cut", "12", "-ksp_type", "cg"] + TIGHT
-    # contrast 1e6: E inherits the conditioning of A, so the coarse operator action is compared to 1e-7
-    its0, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a0, gen=gen, aptol=1e-7)
-    its1, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a1, gen=gen, aptol=1e-7)
+    its0, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a0, gen=gen)
+    its1, _ = cases.compare_with_oracle(lib, 12, (2, 2, 2), 1, a1, gen=gen, aptol=100 * np.finfo(float).eps * contrast)
     assert its1 <= its0
+    mesh, dec, a, b = cases.grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1, **gen)
+    pc = cases.run_pc(lib, mesh, dec, a1, b)
+    e = pc.E()
+    assert np.linalg.cond(e) < 1e3                     # the coarse operator is NOT the ill-conditioned object
+    zb = np.random.default_rng(0).random(e.shape[0])
+    assert np.linalg.norm(e @ np.linalg.solve(e, zb) - zb) <= 1e-13 * np.linalg.norm(zb)
+    pc.destroy()
 
 
 def test_solution_1e10(lib):
