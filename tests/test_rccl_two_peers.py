@@ -21,7 +21,15 @@ import cases
 from oracle import geneo_oracle as go
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests", "rccl_standin"))
+
+
+def build_standin():
+    """tests/rccl_standin/build_standin.py, loaded by path (tests/hostsim has a build.py of its own on sys.path)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("geneo_rccl_standin_build", os.path.join(ROOT, "tests", "rccl_standin", "build_standin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
 
 
 def free_port():
@@ -35,8 +43,7 @@ def free_port():
 @pytest.mark.parametrize("lvl,ksp,parts", [("SRAS,1", "cg", (2, 1, 1)),        # one subdomain per rank: bench.py's N > 1 layout
                                            ("RAS,H1", "gmres", (2, 2, 2))])      # four per rank, hybrid: every operator
 def test_cpp_rccl_transport_two_peers_matches_serial_oracle(tmp_path, lvl, ksp, parts):
-    import build as standin_build
-    standin = standin_build.build()
+    standin = build_standin()
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", GENEO_WORKER_LIB="rccl_standin",
                GENEO_RCCL_LIBRARY=standin)
