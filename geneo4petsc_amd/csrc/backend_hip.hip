@@ -620,34 +620,86 @@ Csr csr_remap_columns(const Csr& a, const int* map_dev) {
 // (k, l) order, so every sum has a fixed order whatever the hash did.  Capacity: SPG_MAXD distinct columns per row.
 constexpr int SPG_HS = 1024;     // hash slots per wave (load factor <= 0.25)
 constexpr int SPG_MAXD = 256;    // distinct columns per output row
-__device__ __forceinline__ void spg_collect(const int* __restrict__ arp, const int* __restrict__ acol,
-                                            const int* __restrict__ brp, const int* __restrict__ bcol, int row,
-                                            int lane, int* keys, int* overflow) {
-  for (int s = lane; s < SPG_HS; s += 64) keys[s] = -1;
+constexpr int SPG_KMAX = 256;    // entries of a row of A whose product offsets fit the wave's LDS prefix table
+constexpr int SPG_CHUNK = 256;   // products staged per round of the numeric phase
+// Round 3: the products of an output row are FLATTENED over the wave.  Round 2 walked the row of A entry by entry and let
+// the lanes stride over the matching row of B -- with the 5-to-30-entry rows of P, A P and R that kept 5 to 30 of 64
+// lanes busy in the symbolic pass, and the numeric pass fetched every product's (column, value) from global memory inside
+// a serial loop (1 250 products per row of R (A P) at 126^3).  Now a prefix table of the B-row lengths (LDS, one entry per
+// entry of the A row) maps product number p to (k, l); lane t takes the products t, t + 64, ...: the hash inserts of the
+// symbolic pass run 64 wide, and the numeric pass stages SPG_CHUNK products at a time in LDS (all lanes loading) before
+// the owner-computes scan reads them back as LDS broadcasts.  Product order (k-major, l-minor) and therefore every sum
+// is unchanged: results are bit-identical to round 2's.  Rows of A longer than SPG_KMAX keep the serial walk.
+__device__ __forceinline__ int spg_prefix(const int* __restrict__ arp, const int* __restrict__ acol, const int* __restrict__ brp,
+                                          int row, int lane, int* ja, int* pre) {
+  const int a0 = arp[row], na = arp[row + 1] - a0;
+  if (na > SPG_KMAX) return -1;
+  for (int k = lane; k < na; k += 64) {
+    const int j = acol[a0 + k];
+    ja[k] = j;
+    pre[k + 1] = brp[j + 1] - brp[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (int k = arp[row]; k < arp[row + 1]; ++k) {
-    const int j = acol[k];
-    for (int l = brp[j] + lane; l < brp[j + 1]; l += 64) {
-      const int key = bcol[l];
-      unsigned h = ((unsigned)key * 2654435761u) & (SPG_HS - 1);
-      for (int probe = 0; probe < SPG_HS; ++probe) {
-        const int old = atomicCAS(&keys[h], -1, key);
-        if (old == -1 || old == key) break;
-        h = (h + 1) & (SPG_HS - 1);
-        if (probe == SPG_HS - 1) *overflow = 1;
-      }
+  if (lane == 0) {
+    pre[0] = 0;
+    for (int k = 0; k < na; ++k) pre[k + 1] += pre[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return pre[na];
+}
+// entry k of the A row that product p belongs to: pre[k] <= p < pre[k + 1]
+__device__ __forceinline__ int spg_find(const int* pre, int na, int p) {
+  int lo = 0, hi = na;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] <= p) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ void spg_insert(int* keys, int key, int* overflow) {
+  unsigned h = ((unsigned)key * 2654435761u) & (SPG_HS - 1);
+  for (int probe = 0; probe < SPG_HS; ++probe) {
+    const int old = atomicCAS(&keys[h], -1, key);
+    if (old == -1 || old == key) break;
+    h = (h + 1) & (SPG_HS - 1);
+    if (probe == SPG_HS - 1) *overflow = 1;
+  }
+}
+// hash set of the distinct columns of output row `row`; returns the number of products (-1: long row, serial walk taken)
+__device__ __forceinline__ int spg_collect(const int* __restrict__ arp, const int* __restrict__ acol,
+                                           const int* __restrict__ brp, const int* __restrict__ bcol, int row,
+                                           int lane, int* keys, int* ja, int* pre, int* overflow) {
+  for (int s = lane; s < SPG_HS; s += 64) keys[s] = -1;
+  const int total = spg_prefix(arp, acol, brp, row, lane, ja, pre);
+  if (total >= 0) {
+    const int na = arp[row + 1] - arp[row];
+    for (int p = lane; p < total; p += 64) {
+      const int k = spg_find(pre, na, p);
+      spg_insert(keys, bcol[brp[ja[k]] + (p - pre[k])], overflow);
+    }
+  } else {
+    for (int k = arp[row]; k < arp[row + 1]; ++k) {
+      const int j = acol[k];
+      for (int l = brp[j] + lane; l < brp[j + 1]; l += 64) spg_insert(keys, bcol[l], overflow);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  return total;
 }
 __global__ __launch_bounds__(256) void k_spgemm_count(int n, const int* __restrict__ arp, const int* __restrict__ acol,
                                                       const int* __restrict__ brp, const int* __restrict__ bcol,
                                                       int* __restrict__ cnt, int* __restrict__ overflow) {
   __shared__ int keys[4][SPG_HS];
+  __shared__ int ja[4][SPG_KMAX];
+  __shared__ int pre[4][SPG_KMAX + 1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
-  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], overflow);
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], overflow);
   int c = 0;
   for (int s = lane; s < SPG_HS; s += 64) c += (keys[w][s] != -1) ? 1 : 0;
 #pragma unroll
@@ -679,13 +731,16 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
                                                      const int* __restrict__ bcol, const double* __restrict__ bval,
                                                      const int* __restrict__ crp, int* __restrict__ ccol,
                                                      double* __restrict__ cval, int* __restrict__ overflow) {
-  __shared__ int keys[4][SPG_HS];
+  __shared__ __attribute__((aligned(16))) int keys[4][SPG_HS];
   __shared__ int list[4][SPG_MAXD];
+  __shared__ int ja[4][SPG_KMAX];
+  __shared__ int pre[4][SPG_KMAX + 1];
   __shared__ int cntl[4];
+  static_assert(SPG_CHUNK * 12 <= SPG_HS * 4, "the staging tiles live in the hash table's LDS");
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
-  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], overflow);
+  const int total = spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], overflow);
   const int base = crp[row], cnt = crp[row + 1] - base;
   if (cnt > SPG_MAXD) return;   // flagged by the count pass
   if (lane == 0) cntl[w] = 0;
@@ -708,15 +763,60 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
     acc[u] = 0.0;
   }
   const int nu = (cnt + 63) >> 6;
-  for (int k = arp[row]; k < arp[row + 1]; ++k) {
-    const int j = acol[k];
-    const double av = aval[k];
-    for (int l = brp[j]; l < brp[j + 1]; ++l) {      // every lane walks the whole row of B: broadcast loads
-      const int key = bcol[l];
-      const double v = av * bval[l];
+  if (total >= 0) {
+    // the hash table has done its job (its keys are in `list`, sorted): its LDS now holds the staging tiles
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int* skey = keys[w];
+    double* sval = reinterpret_cast<double*>(keys[w] + SPG_CHUNK);
+    const int a0 = arp[row], na = arp[row + 1] - a0;
+    for (int p0 = 0; p0 < total; p0 += SPG_CHUNK) {
+      const int nc = (total - p0 < SPG_CHUNK) ? total - p0 : SPG_CHUNK;
+      for (int q = lane; q < nc; q += 64) {          // stage: every lane fetches its own products
+        const int p = p0 + q;
+        const int k = spg_find(pre[w], na, p);
+        const int l = brp[ja[w][k]] + (p - pre[w][k]);
+        skey[q] = bcol[l];
+        sval[q] = aval[a0 + k] * bval[l];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // owner computes, products in their fixed order; eight (key, value) pairs are read per round (LDS broadcasts, all
+      // in flight together) so that the LDS latency is paid once per eight products
+      int q = 0;
+      for (; q + 8 <= nc; q += 8) {
+        int kk[8];
+        double vv[8];
 #pragma unroll
-      for (int u = 0; u < SPG_MAXD / 64; ++u)
-        if (u < nu && key == mycol[u]) acc[u] += v;
+        for (int t = 0; t < 8; ++t) { kk[t] = skey[q + t]; vv[t] = sval[q + t]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+          for (int u = 0; u < SPG_MAXD / 64; ++u)
+            if (u < nu && kk[t] == mycol[u]) acc[u] += vv[t];
+        }
+      }
+      for (; q < nc; ++q) {
+        const int key = skey[q];
+        const double v = sval[q];
+#pragma unroll
+        for (int u = 0; u < SPG_MAXD / 64; ++u)
+          if (u < nu && key == mycol[u]) acc[u] += v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    for (int k = arp[row]; k < arp[row + 1]; ++k) {
+      const int j = acol[k];
+      const double av = aval[k];
+      for (int l = brp[j]; l < brp[j + 1]; ++l) {      // every lane walks the whole row of B: broadcast loads
+        const int key = bcol[l];
+        const double v = av * bval[l];
+#pragma unroll
+        for (int u = 0; u < SPG_MAXD / 64; ++u)
+          if (u < nu && key == mycol[u]) acc[u] += v;
+      }
     }
   }
 #pragma unroll
@@ -728,16 +828,110 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
     }
   }
 }
-static void host_exclusive_scan(int* dcnt_to_ptr, int n, int64_t* total) {   // rowptr[0..n] from counts in rowptr[1..n]
-  std::vector<int> h((size_t)n + 1, 0);
-  d2h(h.data() + 1, dcnt_to_ptr + 1, sizeof(int) * (size_t)n);
-  int64_t run = 0;
-  for (int i = 1; i <= n; ++i) {
-    run += h[i];
-    h[i] = (int)run;
+// rowptr[0..n] from the counts in rowptr[1..n]: inclusive scan on the device (round 2 took the counts to the host and back:
+// two copies of n integers and a serial loop per product -- 10 ms per call at 6.5 M rows, four calls per level).
+// Three-phase scan: 1024-element blocks (LDS), their totals scanned by the same kernel recursively, totals added back.
+constexpr int SCAN_B = 1024;
+__global__ __launch_bounds__(256) void k_scan_blocks(int* __restrict__ x, int64_t n, int64_t* __restrict__ totals) {
+  __shared__ int64_t part[256];
+  const int64_t b0 = (int64_t)blockIdx.x * SCAN_B;
+  const int t = threadIdx.x;
+  int64_t v[4], run = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = b0 + 4 * t + u;
+    run += (i < n) ? x[i] : 0;
+    v[u] = run;
   }
-  h[0] = 0;
-  h2d(dcnt_to_ptr, h.data(), sizeof(int) * ((size_t)n + 1));
+  part[t] = run;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {           // Hillis-Steele over the 256 thread totals
+    const int64_t add = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const int64_t before = (t > 0) ? part[t - 1] : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = b0 + 4 * t + u;
+    if (i < n) x[i] = (int)(before + v[u]);
+  }
+  if (t == 255) totals[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(256) void k_scan_blocks64(int64_t* __restrict__ x, int64_t n, int64_t* __restrict__ totals) {
+  __shared__ int64_t part[256];
+  const int64_t b0 = (int64_t)blockIdx.x * SCAN_B;
+  const int t = threadIdx.x;
+  int64_t v[4], run = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = b0 + 4 * t + u;
+    run += (i < n) ? x[i] : 0;
+    v[u] = run;
+  }
+  part[t] = run;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int64_t add = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const int64_t before = (t > 0) ? part[t - 1] : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = b0 + 4 * t + u;
+    if (i < n) x[i] = before + v[u];
+  }
+  if (t == 255) totals[blockIdx.x] = part[255];
+}
+__global__ void k_scan_add(int* __restrict__ x, int64_t n, const int64_t* __restrict__ totals_incl) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + SCAN_B; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] += (int)totals_incl[i / SCAN_B - 1];
+}
+__global__ void k_scan_add64(int64_t* __restrict__ x, int64_t n, const int64_t* __restrict__ totals_incl) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + SCAN_B; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] += totals_incl[i / SCAN_B - 1];
+}
+static void device_inclusive_scan64(int64_t* x, int64_t n) {       // block totals of a large scan (n <= a few 10^4)
+  if (n <= 0) return;
+  const int64_t nb = (n + SCAN_B - 1) / SCAN_B;
+  int64_t* tot = (int64_t*)alloc(sizeof(int64_t) * (size_t)nb);
+  hipLaunchKernelGGL(k_scan_blocks64, dim3((unsigned)nb), dim3(256), 0, g_stream, x, n, tot);
+  if (nb > 1) {
+    device_inclusive_scan64(tot, nb);
+    hipLaunchKernelGGL(k_scan_add64, dim3((unsigned)std::min<int64_t>(nb, 4096)), dim3(256), 0, g_stream, x, n, tot);
+  }
+  dfree(tot);
+}
+static void host_exclusive_scan(int* dcnt_to_ptr, int n, int64_t* total) {   // rowptr[0..n] from counts in rowptr[1..n]
+  if (n <= 0) { *total = 0; return; }
+  static const bool on_host = getenv("GENEO_SCAN_HOST") != nullptr;
+  if (on_host || (int64_t)n < 4 * SCAN_B) {
+    std::vector<int> h((size_t)n + 1, 0);
+    d2h(h.data() + 1, dcnt_to_ptr + 1, sizeof(int) * (size_t)n);
+    int64_t run = 0;
+    for (int i = 1; i <= n; ++i) {
+      run += h[i];
+      h[i] = (int)run;
+    }
+    h[0] = 0;
+    h2d(dcnt_to_ptr, h.data(), sizeof(int) * ((size_t)n + 1));
+    *total = run;
+    return;
+  }
+  int* x = dcnt_to_ptr + 1;
+  const int64_t nb = ((int64_t)n + SCAN_B - 1) / SCAN_B;
+  int64_t* tot = (int64_t*)alloc(sizeof(int64_t) * (size_t)nb);
+  hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nb), dim3(256), 0, g_stream, x, (int64_t)n, tot);
+  device_inclusive_scan64(tot, nb);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)std::min<int64_t>(nb, 4096)), dim3(256), 0, g_stream, x, (int64_t)n, tot);
+  HIPCHK(hipMemsetAsync(dcnt_to_ptr, 0, sizeof(int), g_stream));
+  int64_t run = 0;
+  d2h(&run, tot + (nb - 1), sizeof(int64_t));
+  dfree(tot);
+  if (run > 0x7fffffffLL) throw std::runtime_error("sparse product: more than 2^31 entries");
   *total = run;
 }
 Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
