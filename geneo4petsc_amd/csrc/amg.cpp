@@ -535,8 +535,33 @@ void AmgDevice::alloc_level_buffers(Lvl& L, bool coarse) {
   }
 }
 
+AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& so, const AmgParams& prm, int l) {
+  AmgLevelHostPart h;
+  const int nsub = (int)so.size() - 1;
+  h.rho = gershgorin_rho(Ah, h.dinv);
+  int maxblk = 0;
+  for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, so[s + 1] - so[s]);
+  h.last = (maxblk <= prm.coarse_size || l + 1 >= prm.max_levels);
+  h.csub.assign(nsub + 1, 0);
+  if (!h.last) {  // aggregation per subdomain block, on the host
+    const int n = Ah.n;
+    h.agg.assign(n, -1);
+    std::vector<int> nagg(nsub, 0);
+    std::vector<std::thread> th;
+    for (int s = 0; s < nsub; ++s)
+      th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], h.agg, amg_strength(prm, l)); });
+    for (auto& x : th) x.join();
+    for (int s = 0; s < nsub; ++s) h.csub[s + 1] = h.csub[s] + nagg[s];
+    for (int s = 0; s < nsub; ++s)
+      for (int i = so[s]; i < so[s + 1]; ++i) h.agg[i] += h.csub[s];
+    h.nc = h.csub[nsub];
+    if (h.nc >= n) h.last = true;
+  }
+  return h;
+}
+
 bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& p, int max_m,
-                                const bk::Csr* fine_dev) {
+                                const bk::Csr* fine_dev, const AmgLevelHostPart* level0) {
   free_all();
   prm = p;
   maxm = std::max(1, max_m);
@@ -563,31 +588,20 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     L.n = Ah.n;
     L.A = Adev;
     L.own_A = own;
-    std::vector<double> dinv;
-    L.rho = gershgorin_rho(Ah, dinv);
+    // host part of the level (diagonal, Gershgorin bound, aggregates): level 0 may have been computed early by the caller
+    AmgLevelHostPart hp_own;
+    if (!(l == 0 && level0)) hp_own = amg_level_host_part(Ah, so, prm, l);
+    const AmgLevelHostPart& hp = (l == 0 && level0) ? *level0 : hp_own;
+    const std::vector<double>& dinv = hp.dinv;
+    L.rho = hp.rho;
     L.dinv = (double*)bk::alloc(sizeof(double) * std::max(1, L.n));
     bk::h2d(L.dinv, dinv.data(), sizeof(double) * L.n);
     if (l == 0) nnz0 = (double)Ah.val.size();
     nnzt += (double)Ah.val.size();
-    int maxblk = 0;
-    for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, so[s + 1] - so[s]);
-    bool last = (maxblk <= prm.coarse_size || l + 1 >= prm.max_levels);
-    std::vector<int> agg, csub(nsub + 1, 0);
-    int nc = 0;
-    if (!last) {  // aggregation per subdomain block, on the host
-      const int n = Ah.n;
-      agg.assign(n, -1);
-      std::vector<int> nagg(nsub, 0);
-      std::vector<std::thread> th;
-      for (int s = 0; s < nsub; ++s)
-        th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], agg, amg_strength(prm, l)); });
-      for (auto& x : th) x.join();
-      for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
-      for (int s = 0; s < nsub; ++s)
-        for (int i = so[s]; i < so[s + 1]; ++i) agg[i] += csub[s];
-      nc = csub[nsub];
-      if (nc >= n) last = true;
-    }
+    const bool last = hp.last;
+    const std::vector<int>& agg = hp.agg;
+    const std::vector<int>& csub = hp.csub;
+    const int nc = hp.nc;
     auto t_1 = tnow();
     if (last) {
       alloc_level_buffers(L, l > 0);

@@ -37,6 +37,18 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
                     std::vector<AmgLevelHost>& levels, std::vector<double>& coarse_inv,
                     std::vector<int64_t>& coarse_base);
 
+// Host part of one level of a device-built hierarchy: Jacobi diagonal + Gershgorin bound, aggregates per subdomain
+// block.  Level 0 needs nothing but the caller's host matrix, so the set-up computes it EARLY, on its own thread, while
+// the matrices are still being uploaded (amg_level_host_part is what AmgDevice::build_on_device runs per level otherwise).
+struct AmgLevelHostPart {
+  std::vector<double> dinv;
+  double rho = 2.0;
+  std::vector<int> agg, csub;     // aggregate of every row (global numbering of the coarse level), block offsets
+  int nc = 0;
+  bool last = false;              // no further coarsening from this level
+};
+AmgLevelHostPart amg_level_host_part(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm, int level);
+
 // null pivots detected and fixed in the dense coarsest blocks (singular subdomain matrices: tuneSolver, geneo.cpp:76-92)
 // by the hierarchies built since the last call
 int amg_null_pivots_take();
@@ -54,7 +66,7 @@ class AmgDevice {
   // HBM.  Returns false (nothing built) when a row exceeds the product kernels' capacity: the caller then takes
   // amg_setup_host + upload.
   bool build_on_device(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& prm, int max_m,
-                       const bk::Csr* fine_dev);
+                       const bk::Csr* fine_dev, const AmgLevelHostPart* level0 = nullptr);
   // X = V(B) with zero initial guess; B, X: n0 x m row-major with leading dimensions ldb / ldx
   void vcycle(const double* B, int ldb, double* X, int ldx, int m);
   int nlevels() const { return (int)lv.size(); }

@@ -25,6 +25,7 @@
 #include <exception>
 #include <mutex>
 #include <functional>
+#include <future>
 #include <map>
 #include <numeric>
 #include <fstream>
@@ -195,6 +196,7 @@ struct AmgHostResult {
 struct PC::Amg1Pending {
   HostCsr mat;
   AmgHostResult res;
+  std::future<AmgLevelHostPart> level0;   // diagonal + aggregates of the fine level, started as soon as `mat` exists
   AmgDevice* dev = nullptr;     // built / uploaded by the same thread on its side stream (handed to PC::amg1 at the join)
   double upload_secs = 0.0;
   bool on_device = false;       // sparse products on the device (host: aggregation only)
@@ -637,6 +639,17 @@ int PC::setup(const double* b_dev) {
   const bool want1 = (opt.dls1_pc == "amg");
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
   const AmgParams ap = amg_params(opt);
+  AmgParams ap1h = ap;                      // the level-1 hierarchy (local solves): its own aggregation strength
+  ap1h.strength = opt.dls1_amg_strength;
+  AmgParams apN = ap;                       // the A_Neu hierarchy (LOBPCG preconditioner)
+  apN.strength = opt.els2_amg_strength;
+  // The host part of the fine level of both hierarchies (Jacobi diagonal, Gershgorin bound, aggregates) needs nothing
+  // but the host matrices: it runs on its own threads from here on, behind the uploads and the diagonals (with ONE
+  // 6.5 M-row subdomain per GPU it is 0.08-0.1 s per hierarchy of a single thread).
+  const bool early0 = !getenv("GENEO_AMG_HOST") && !getenv("GENEO_AMG_LATE_LEVEL0");
+  std::future<AmgLevelHostPart> pre_neu;
+  if (wantN && early0)
+    pre_neu = std::async(std::launch::async, [&h_neuL, this, apN]() { return amg_level_host_part(h_neuL, suboff, apN, 0); });
   auto tdbg = clk::now();
   auto lap = [&](const char* what) {
     if (!getenv("GENEO_DEBUG")) return;
@@ -661,7 +674,16 @@ int PC::setup(const double* b_dev) {
     }
   }
   lap("A_Dir blockdiag (joined)");
-  dirL = upload_host(h_dirL);
+  pend1.reset(want1 ? new Amg1Pending() : nullptr);
+  if (want1) {
+    pend1->mat = std::move(h_dirL);
+    if (early0 && !getenv("GENEO_AMG1_HOST")) {
+      Amg1Pending* pp = pend1.get();
+      const std::vector<int> so = suboff;
+      pend1->level0 = std::async(std::launch::async, [pp, so, ap1h]() { return amg_level_host_part(pp->mat, so, ap1h, 0); });
+    }
+  }
+  dirL = upload_host(want1 ? pend1->mat : h_dirL);
   dirL.fine = true;
   // 16-bit column offsets per slice (+ float values for the V-cycle): the FP64 SpMV of the local solves then reads
   // 10 bytes per entry instead of 12; the level-1 hierarchy borrows this companion instead of making its own
@@ -732,12 +754,6 @@ int PC::setup(const double* b_dev) {
     // with the eigensolve; it is joined and uploaded when level 2 is done (or right away without level 2).
     lap("diagonals");
     auto ta = clk::now();
-    pend1.reset(want1 ? new Amg1Pending() : nullptr);
-    if (want1) pend1->mat = std::move(h_dirL);
-    AmgParams ap1h = ap;                      // the level-1 hierarchy (local solves): its own aggregation strength
-    ap1h.strength = opt.dls1_amg_strength;
-    AmgParams apN = ap;                       // the A_Neu hierarchy (LOBPCG preconditioner)
-    apN.strength = opt.els2_amg_strength;
     // GenEO-2 runs the gamma eigenproblem through this hierarchy with whole blocks
     const int max_m1 = (opt.lvl2 == 2 && opt.els2_pc == "amg") ? eig_block_max() : 1;
     auto start1 = [this, ap1h, max_m1]() {
@@ -757,7 +773,12 @@ int PC::setup(const double* b_dev) {
           bk::side_stream_begin();
           pp->dev = new AmgDevice();
           bool built = false;
-          if (!getenv("GENEO_AMG1_HOST") && !getenv("GENEO_AMG_HOST")) built = pp->dev->build_on_device(pp->mat, so, ap, max_m1, fine);
+          if (!getenv("GENEO_AMG1_HOST") && !getenv("GENEO_AMG_HOST")) {
+            AmgLevelHostPart l0;
+            const bool have0 = pp->level0.valid();
+            if (have0) l0 = pp->level0.get();
+            built = pp->dev->build_on_device(pp->mat, so, ap, max_m1, fine, have0 ? &l0 : nullptr);
+          }
           pp->res.secs = secs(t0, clk::now());
           pp->on_device = built;
           if (!built) {
@@ -786,7 +807,12 @@ int PC::setup(const double* b_dev) {
       try {
         amgN = new AmgDevice();
         bool built = false;
-        if (!getenv("GENEO_AMG_HOST")) built = amgN->build_on_device(h_neuL, suboff, apN, eig_block_max(), &neuL);
+        if (!getenv("GENEO_AMG_HOST")) {
+          AmgLevelHostPart l0;
+          const bool have0 = pre_neu.valid();
+          if (have0) l0 = pre_neu.get();
+          built = amgN->build_on_device(h_neuL, suboff, apN, eig_block_max(), &neuL, have0 ? &l0 : nullptr);
+        }
         if (!built) {
           AmgHostResult rN;
           amg_setup_host(h_neuL, suboff, apN, rN.levels, rN.cinv, rN.cbase);
