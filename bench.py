@@ -517,6 +517,7 @@ def main():
         ndof = n ** 3
     comm = None
     comm_name = "none"
+    transport_fallback = None      # set when the C++ RCCL transport could not start and torch.distributed carried the run
     if size > 1:
         from geneo4petsc_amd import comm as gcomm
         if staged:
@@ -525,6 +526,7 @@ def main():
             try:
                 comm, comm_name = gcomm.RcclComm(plan, lib, dist, torch.device("cuda", local_rank)), "rccl (C++ transport in libgeneopc)"
             except RuntimeError as e:      # raised on every rank together (comm.RcclComm agrees first): same fallback everywhere
+                transport_fallback = str(e)
                 if rank == 0:
                     print("bench.py: %s -- falling back to the torch.distributed transport" % e, file=sys.stderr, flush=True)
                 comm, comm_name = gcomm.TorchComm(plan, torch.device("cuda", local_rank)), "torch.distributed (nccl backend; the C++ RCCL transport failed to start)"
@@ -667,6 +669,7 @@ def main():
             "value": agg_gbs, "unit": "GB/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "transport_fallback": transport_fallback,      # not None: this is NOT a measurement of the C++ RCCL transport
             "config": {"workload": (wl_desc + ", -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e"
                                     % (args.lvl, args.cut, args.tau, args.eps_tol, args.rtol)) if wl_desc else
                                    "3D 7-pt Laplacian (reference tst/laplacian generator, kappa=1, eps=1e-4; the reference has "
