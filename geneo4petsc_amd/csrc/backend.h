@@ -139,6 +139,8 @@ bool csr_fusable(const Csr& a);   // no long-row remainder and the sliced layout
 void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
                 double* Z, int ldz, const double* dinv, double w);
 void csr_diag(const Csr& a, double* diag);
+// x[i] <- 1 / x[i] in place; returns the number of entries that are not > 0 (those are left untouched)
+int  recip_positive(double* x, int n);
 
 // ---- index kernels -------------------------------------------------------------------------
 void gather(double* out, const double* in, const int* idx, int n);                       // out[i]=in[idx[i]]

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <string>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <thread>
 #include <map>
@@ -214,40 +215,77 @@ void alloc_stats(double* alloc_s, double* free_s, long long* n) {
 // go through two pinned staging buffers: the host memcpy of one chunk overlaps the DMA of the other.  Small
 // transfers take the plain path (their cost is the synchronisation, not the bandwidth).
 constexpr size_t STAGE_BYTES = (size_t)16 << 20;
-static char* g_stage[2] = {nullptr, nullptr};
-static hipEvent_t g_stage_ev[2];
-static bool stage_ready() {
-  if (g_stage[0]) return true;
-  if (getenv("GENEO_NO_PINNED_STAGING")) return false;
-  for (int i = 0; i < 2; ++i) {
-    if (hipHostMalloc((void**)&g_stage[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      if (i == 1) (void)hipHostFree(g_stage[0]);
-      g_stage[0] = g_stage[1] = nullptr;
-      return false;
+// Two staging sets (two pinned buffers + events each): a thread takes a free set for the duration of one large copy, so
+// the main thread and a side-stream thread (section "side streams") stage their uploads side by side -- the host memcpy
+// into pinned memory, ~10 GB/s per thread, is what bounds a pageable upload, not the link.
+struct StageSet {
+  char* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2];
+  bool ready = false, busy = false, failed = false;
+};
+static StageSet g_stage_sets[2];
+static std::mutex g_stage_mu;
+static std::condition_variable g_stage_cv;
+static StageSet* stage_acquire() {
+  if (getenv("GENEO_NO_PINNED_STAGING")) return nullptr;
+  std::unique_lock<std::mutex> lk(g_stage_mu);
+  for (;;) {
+    bool any_usable = false;
+    for (StageSet& st : g_stage_sets) {
+      if (st.failed) continue;
+      any_usable = true;
+      if (st.busy) continue;
+      if (!st.ready) {
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i) {
+          if (hipHostMalloc((void**)&st.buf[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (i == 1) (void)hipHostFree(st.buf[0]);
+            st.buf[0] = st.buf[1] = nullptr;
+            ok = false;
+          } else if (hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming) != hipSuccess) {
+            ok = false;
+          }
+        }
+        if (!ok) { st.failed = true; continue; }
+        st.ready = true;
+      }
+      st.busy = true;
+      return &st;
     }
-    HIPCHK(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+    if (!any_usable) return nullptr;
+    g_stage_cv.wait(lk);
   }
-  return true;
 }
-static std::mutex g_stage_mu;    // the two pinned buffers are shared by the threads that copy (main + side stream)
+static void stage_release(StageSet* st) {
+  {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    st->busy = false;
+  }
+  g_stage_cv.notify_one();
+}
+struct StageGuard {
+  StageSet* st;
+  explicit StageGuard(StageSet* s) : st(s) {}
+  ~StageGuard() { if (st) stage_release(st); }
+};
 void h2d(void* d, const void* h, size_t bytes) {
   if (!bytes) return;
   if (bytes >= 2 * STAGE_BYTES && !g_capturing) {
-   std::lock_guard<std::mutex> lk(g_stage_mu);
-   if (stage_ready()) {
-    size_t off = 0;
-    for (int i = 0; off < bytes; ++i, off += STAGE_BYTES) {
-      const int b = i & 1;
-      const size_t len = std::min(STAGE_BYTES, bytes - off);
-      if (i >= 2) HIPCHK(hipEventSynchronize(g_stage_ev[b]));      // the DMA that last used this buffer is done
-      std::memcpy(g_stage[b], (const char*)h + off, len);
-      HIPCHK(hipMemcpyAsync((char*)d + off, g_stage[b], len, hipMemcpyHostToDevice, g_stream));
-      HIPCHK(hipEventRecord(g_stage_ev[b], g_stream));
+    StageGuard g(stage_acquire());
+    if (g.st) {
+      size_t off = 0;
+      for (int i = 0; off < bytes; ++i, off += STAGE_BYTES) {
+        const int b = i & 1;
+        const size_t len = std::min(STAGE_BYTES, bytes - off);
+        if (i >= 2) HIPCHK(hipEventSynchronize(g.st->ev[b]));      // the DMA that last used this buffer is done
+        std::memcpy(g.st->buf[b], (const char*)h + off, len);
+        HIPCHK(hipMemcpyAsync((char*)d + off, g.st->buf[b], len, hipMemcpyHostToDevice, g_stream));
+        HIPCHK(hipEventRecord(g.st->ev[b], g_stream));
+      }
+      HIPCHK(hipStreamSynchronize(g_stream));
+      return;
     }
-    HIPCHK(hipStreamSynchronize(g_stream));
-    return;
-   }
   }
   HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));  // h may be pageable / reused by the caller
@@ -255,23 +293,23 @@ void h2d(void* d, const void* h, size_t bytes) {
 void d2h(void* h, const void* d, size_t bytes) {
   if (!bytes) return;
   if (bytes >= 2 * STAGE_BYTES && !g_capturing) {
-   std::lock_guard<std::mutex> lk(g_stage_mu);
-   if (stage_ready()) {
-    const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
-    auto issue = [&](size_t i) {
-      const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
-      HIPCHK(hipMemcpyAsync(g_stage[i & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, g_stream));
-      HIPCHK(hipEventRecord(g_stage_ev[i & 1], g_stream));
-    };
-    issue(0);
-    for (size_t i = 0; i < nchunk; ++i) {
-      if (i + 1 < nchunk) issue(i + 1);                             // next chunk's DMA runs during this memcpy
-      HIPCHK(hipEventSynchronize(g_stage_ev[i & 1]));
-      const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
-      std::memcpy((char*)h + off, g_stage[i & 1], len);
+    StageGuard g(stage_acquire());
+    if (g.st) {
+      const size_t nchunk = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+      auto issue = [&](size_t i) {
+        const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
+        HIPCHK(hipMemcpyAsync(g.st->buf[i & 1], (const char*)d + off, len, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipEventRecord(g.st->ev[i & 1], g_stream));
+      };
+      issue(0);
+      for (size_t i = 0; i < nchunk; ++i) {
+        if (i + 1 < nchunk) issue(i + 1);                             // next chunk's DMA runs during this memcpy
+        HIPCHK(hipEventSynchronize(g.st->ev[i & 1]));
+        const size_t off = i * STAGE_BYTES, len = std::min(STAGE_BYTES, bytes - off);
+        std::memcpy((char*)h + off, g.st->buf[i & 1], len);
+      }
+      return;
     }
-    return;
-   }
   }
   HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
@@ -2253,6 +2291,24 @@ void csr_diag(const Csr& a, double* diag) {
   if (a.n == 0) return;
   hipLaunchKernelGGL(k_csr_diag, dim3(grid1d(a.n, 256)), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val,
                      diag);
+}
+__global__ void k_recip_positive(double* __restrict__ x, int n, int* __restrict__ bad) {
+  int mine = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = x[i];
+    if (v > 0.0) x[i] = 1.0 / v;
+    else ++mine;
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+int recip_positive(double* x, int n) {
+  if (n <= 0) return 0;
+  int* dbad = (int*)alloc(sizeof(int));
+  hipLaunchKernelGGL(k_recip_positive, dim3(gridv(n)), dim3(256), 0, g_stream, x, n, dbad);
+  int h = 0;
+  d2h(&h, dbad, sizeof(int));
+  dfree(dbad);
+  return h;
 }
 
 // =============================================================================== index kernels

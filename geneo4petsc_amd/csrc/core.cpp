@@ -194,7 +194,9 @@ struct AmgHostResult {
 };
 
 struct PC::Amg1Pending {
-  HostCsr mat;
+  HostCsr mat_own;                        // block-diagonal host copy of the level-1 matrix (several subdomains) ...
+  const HostCsr* matp = nullptr;          // ... or the ONE subdomain's own matrix, used where it lies (no copy)
+  const HostCsr& mat() const { return *matp; }
   AmgHostResult res;
   std::future<AmgLevelHostPart> level0;   // diagonal + aggregates of the fine level, started as soon as `mat` exists
   AmgDevice* dev = nullptr;     // built / uploaded by the same thread on its side stream (handed to PC::amg1 at the join)
@@ -625,17 +627,31 @@ int PC::setup(const double* b_dev) {
   }
   auto t1 = clk::now();
   // the level-1 block-diagonal matrix is assembled on its own thread while this one assembles and uploads A_Neu
-  HostCsr h_dirL;
+  // With ONE subdomain on this rank (the N > 1 layout of bench.py: a 6.5 M-row block) the block-diagonal matrices ARE the
+  // subdomain's: they are used where they lie instead of being copied (0.085 s per matrix at that size).
+  const bool single_block = (ns == 1);
+  HostCsr h_dirL_own, h_neuL_own;
   std::exception_ptr dir_err;      // a bad_alloc on the thread must come back as an error code, not std::terminate
+  // The level-1 matrix is assembled AND uploaded (with its 16-bit column offsets / float values: the FP64 SpMV of the
+  // local solves then reads 10 bytes per entry instead of 12, the level-1 hierarchy borrows the companion) by its own
+  // thread on a side stream, next to the assembly + upload of A_Neu on this one: two staging sets, two host memcpy
+  // streams into pinned memory.
   std::thread dir_thread([&]() {
     try {
-      h_dirL = make_blockdiag(lvl1, suboff, nullptr);
+      if (!single_block) h_dirL_own = make_blockdiag(lvl1, suboff, nullptr);
+      bk::side_stream_begin();
+      dirL = upload_host(single_block ? *lvl1[0] : h_dirL_own);
+      dirL.fine = true;
+      bk::csr_make_lp(dirL);
+      bk::side_stream_end();
     } catch (...) {
+      bk::side_stream_end();
       dir_err = std::current_exception();
     }
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } dir_joiner{dir_thread};
-  HostCsr h_neuL = make_blockdiag(neu, suboff, nullptr);
+  if (!single_block) h_neuL_own = make_blockdiag(neu, suboff, nullptr);
+  const HostCsr& h_neuL = single_block ? *neu[0] : h_neuL_own;
   const bool want1 = (opt.dls1_pc == "amg");
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
   const AmgParams ap = amg_params(opt);
@@ -676,19 +692,18 @@ int PC::setup(const double* b_dev) {
   lap("A_Dir blockdiag (joined)");
   pend1.reset(want1 ? new Amg1Pending() : nullptr);
   if (want1) {
-    pend1->mat = std::move(h_dirL);
+    if (single_block) pend1->matp = lvl1[0];        // subs[0].a_dir or the Robin matrix of this set-up: both outlive the thread
+    else {
+      pend1->mat_own = std::move(h_dirL_own);
+      pend1->matp = &pend1->mat_own;
+    }
     if (early0 && !getenv("GENEO_AMG1_HOST")) {
       Amg1Pending* pp = pend1.get();
       const std::vector<int> so = suboff;
-      pend1->level0 = std::async(std::launch::async, [pp, so, ap1h]() { return amg_level_host_part(pp->mat, so, ap1h, 0); });
+      pend1->level0 = std::async(std::launch::async, [pp, so, ap1h]() { return amg_level_host_part(pp->mat(), so, ap1h, 0); });
     }
   }
-  dirL = upload_host(want1 ? pend1->mat : h_dirL);
-  dirL.fine = true;
-  // 16-bit column offsets per slice (+ float values for the V-cycle): the FP64 SpMV of the local solves then reads
-  // 10 bytes per entry instead of 12; the level-1 hierarchy borrows this companion instead of making its own
-  bk::csr_make_lp(dirL);
-  lap("upload A_Dir");
+  lap("A_Dir uploaded by its thread (joined)");
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {
     std::vector<double> D(std::max(1, nL));
@@ -698,40 +713,35 @@ int PC::setup(const double* b_dev) {
     bk::h2d(d_D, D.data(), sizeof(double) * nL);
     d_dinv1 = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
     d_dinvN = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
-    std::vector<double> dg(std::max(1, nL));
+    // Jacobi diagonals inverted and checked on the device (round 2 took both diagonals to the host and back)
     bk::csr_diag(dirL, d_dinv1);
-    bk::d2h(dg.data(), d_dinv1, sizeof(double) * nL);
-    for (int i = 0; i < nL; ++i) {
-      if (!(dg[i] > 0.0)) return fail("GenEO preconditioner: non-positive diagonal in the local Dirichlet matrix");
-      dg[i] = 1.0 / dg[i];
-    }
-    bk::h2d(d_dinv1, dg.data(), sizeof(double) * nL);
+    if (bk::recip_positive(d_dinv1, nL)) return fail("GenEO preconditioner: non-positive diagonal in the local Dirichlet matrix");
     bk::csr_diag(neuL, d_dinvN);
-    bk::d2h(dg.data(), d_dinvN, sizeof(double) * nL);
-    // Gershgorin bound of the Jacobi-scaled Neumann matrix (Chebyshev interval)
-    double lmax = 0.0;
-    for (int s = 0; s < ns; ++s) {
-      const HostCsr& m = subs[s].a_neu;
-      std::mutex mu;
-      bool nonpos = false;
-      parallel_ranges(m.n, [&](int64_t i0, int64_t i1) {
-        double lm = 0.0;
-        bool np = false;
-        for (int64_t i = i0; i < i1; ++i) {
-          double row = 0.0;
-          for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
-          const double d = dg[suboff[s] + i];
-          if (!(d > 0.0)) { np = true; continue; }
-          lm = std::max(lm, row / d);
-        }
-        std::lock_guard<std::mutex> lk(mu);
-        lmax = std::max(lmax, lm);
-        nonpos = nonpos || np;
-      });
-      if (nonpos) return fail("GenEO preconditioner: non-positive diagonal in the local Neumann matrix");
+    // Gershgorin bounds of the Jacobi-scaled matrices: only the Chebyshev fallbacks of the eigensolves read them
+    const bool need_lmax = opt.lvl2 && (opt.els2_pc != "amg" || opt.check);
+    const bool need_lmax1 = opt.lvl2 == 2 && (opt.els2_pc != "amg" || opt.dls1_pc != "amg");
+    if (need_lmax) {
+      std::vector<double> dg(std::max(1, nL));
+      bk::d2h(dg.data(), d_dinvN, sizeof(double) * nL);
+      double lmax = 0.0;
+      for (int s = 0; s < ns; ++s) {
+        const HostCsr& m = subs[s].a_neu;
+        std::mutex mu;
+        parallel_ranges(m.n, [&](int64_t i0, int64_t i1) {
+          double lm = 0.0;
+          for (int64_t i = i0; i < i1; ++i) {
+            double row = 0.0;
+            for (int k = m.rowptr[i]; k < m.rowptr[i + 1]; ++k) row += std::fabs(m.val[k]);
+            const double d = dg[suboff[s] + i];
+            if (d > 0.0) lm = std::max(lm, row / d);
+          }
+          std::lock_guard<std::mutex> lk(mu);
+          lmax = std::max(lmax, lm);
+        });
+      }
+      cheb_lmax = lmax > 0 ? lmax : 2.0;
     }
-    cheb_lmax = lmax > 0 ? lmax : 2.0;
-    if (opt.lvl2 == 2) {  // same bound for the level-1 (Robin) matrix: Chebyshev fallback of the gamma eigenproblem
+    if (need_lmax1) {  // same bound for the level-1 (Robin) matrix: Chebyshev fallback of the gamma eigenproblem
       std::vector<double> d1(std::max(1, nL));
       bk::d2h(d1.data(), d_dinv1, sizeof(double) * nL);
       double l1 = 0.0;
@@ -745,8 +755,7 @@ int PC::setup(const double* b_dev) {
       }
       cheb_lmax1 = l1 > 0 ? l1 : 2.0;
     }
-    for (int i = 0; i < nL; ++i) dg[i] = 1.0 / dg[i];
-    bk::h2d(d_dinvN, dg.data(), sizeof(double) * nL);
+    if (bk::recip_positive(d_dinvN, nL)) return fail("GenEO preconditioner: non-positive diagonal in the local Neumann matrix");
   }
   {
     // Inner AMG hierarchies: A_Neu (LOBPCG preconditioner) first -- the eigensolve is waiting for it --
@@ -777,12 +786,12 @@ int PC::setup(const double* b_dev) {
             AmgLevelHostPart l0;
             const bool have0 = pp->level0.valid();
             if (have0) l0 = pp->level0.get();
-            built = pp->dev->build_on_device(pp->mat, so, ap, max_m1, fine, have0 ? &l0 : nullptr);
+            built = pp->dev->build_on_device(pp->mat(), so, ap, max_m1, fine, have0 ? &l0 : nullptr);
           }
           pp->res.secs = secs(t0, clk::now());
           pp->on_device = built;
           if (!built) {
-            amg_setup_host(pp->mat, so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
+            amg_setup_host(pp->mat(), so, ap, pp->res.levels, pp->res.cinv, pp->res.cbase);
             pp->res.secs = secs(t0, clk::now());
             auto t1 = clk::now();
             pp->dev->upload(pp->res.levels, pp->res.cinv, pp->res.cbase, ap, max_m1, fine);

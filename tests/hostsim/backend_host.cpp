@@ -199,6 +199,14 @@ void csr_diag(const Csr& a, double* d) {
     d[i] = v;
   }
 }
+int recip_positive(double* x, int n) {
+  int bad = 0;
+  for (int i = 0; i < n; ++i) {
+    if (x[i] > 0.0) x[i] = 1.0 / x[i];
+    else ++bad;
+  }
+  return bad;
+}
 void gather(double* out, const double* in, const int* idx, int n) { for (int i = 0; i < n; ++i) out[i] = in[idx[i]]; }
 void gather_rows(double* out, const double* in, const int* idx, int n, int w) {
   for (int i = 0; i < n; ++i)
