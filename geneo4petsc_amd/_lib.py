@@ -146,6 +146,7 @@ SYMBOLS = {
                       C.c_int, c_dbl_p]),
     "GeneoSpmmFused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_double]),
+    "GeneoSpmmDualTest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "GeneoSpmvFusedSingle": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_double]),
     "GeneoTestLobpcgUpdate": (C.c_int, [C.c_int, c_int_p] + [c_dbl_p] * 11),

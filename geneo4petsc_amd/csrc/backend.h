@@ -113,6 +113,14 @@ bool spmv_profiling();   // between start and stop (callers replay one graph in 
 // Y = post .* (A (pre .* X)); X (ldx), Y (ldy) row-major with m columns; pre/post may be null
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post);
+// Two operators on ONE sliced pattern, one pass over X (LOBPCG's A W and B W): sell_values_on lays the values of b out on
+// a's sliced pattern (device array of a.sl_nnz doubles, zeros where b has no entry; nullptr when pattern(b) is not
+// contained in pattern(a) row by row or a is not on the sliced path); spmm_dual computes Y1 = (a's pattern, v1) X and
+// Y2 = (a's pattern, v2) X, m = 16 | 32 | 64 columns, bit-identical to two separate products.
+double* sell_values_on(const Csr& a, const Csr& b);
+bool spmm_dual_available(const Csr& a, int m);
+void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* Y1, double* Y2, int ldy,
+               int m);
 // Fused epilogues of the multigrid cycle (one launch instead of SpMV + 1-2 vector kernels); blocks are
 // row-major with m columns, m = 1 runs the sliced SpMV kernel.  A must be square for JAC / PRE.
 //   EPI_RES : Y = B - A X

@@ -2208,6 +2208,163 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
   return true;
 }
 
+// ------------------------------------------------------------------------------- two operators, one pass over X
+// Y1 = A1 X and Y2 = A2 X where A1 and A2 share ONE sliced pattern (LOBPCG: A_Neu laid out on A_Dir's pattern -- which
+// contains it -- and D A_Dir D): the X rows, whose gathers are what the sliced SpMM spends its time on, are fetched once
+// for both products.  Same traversal, staging and step groups as k_spmm_sell<LG, EPI_NONE, U>; per entry one more value
+// in LDS and one more FMA pair.  Results are bit-identical to the two separate products: the extra pattern entries of
+// A_Neu carry explicit zeros, which change no sum.
+template <int LG, int U, int KW>
+__device__ __forceinline__ void spmm_sell_accum2(const int* mc, const double* mv1, const double* mv2, int rl0,
+                                                 const double* __restrict__ Xq, int ldx, spmm_d2* acc1, spmm_d2* acc2) {
+  constexpr int RS = 64 / LG;
+  spmm_d2 x[KW][U];
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = mc[k * 64 + rl0 + u * RS];
+      x[k][u] = *reinterpret_cast<const spmm_d2*>(Xq + (int64_t)c * ldx);
+    }
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc1[u] += mv1[k * 64 + rl0 + u * RS] * x[k][u];
+      acc2[u] += mv2[k * 64 + rl0 + u * RS] * x[k][u];
+    }
+}
+template <int LG, int U>
+__global__ __launch_bounds__(256) void k_spmm_sell_dual(const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
+                                                        const double* __restrict__ v1, const double* __restrict__ v2, int n,
+                                                        const int* __restrict__ sched, const int* __restrict__ xptr,
+                                                        const double* __restrict__ X, int ldx, double* __restrict__ Y1,
+                                                        double* __restrict__ Y2, int ldy) {
+  typedef spmm_d2 d2;
+  constexpr int KC = 8;
+  constexpr int RS = 64 / LG;
+  constexpr int NSTEP = 64 / RS;
+  static_assert(NSTEP % U == 0, "steps in flight must divide the steps of a slice");
+  __shared__ int lc[4][KC * 64];
+  __shared__ double lv1[4][KC * 64];
+  __shared__ double lv2[4][KC * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / LG, q = lane % LG;
+  const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  int* mc = lc[wave];
+  double* m1 = lv1[wave];
+  double* m2 = lv2[wave];
+  const double* Xq = X + 2 * q;
+  for (int it = xptr[xg] + slot * 4 + wave; it < xptr[xg + 1]; it += wpx * 4) {
+    const int s = sched ? sched[it] : it;
+    const int64_t base = sl_ptr[s];
+    const int wd = (int)((sl_ptr[s + 1] - base) >> 6);
+    const int nchunk = (wd + KC - 1) / KC;
+    for (int g = 0; g < NSTEP / U; ++g) {
+      d2 acc1[U], acc2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { acc1[u] = d2{0.0, 0.0}; acc2[u] = d2{0.0, 0.0}; }
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int kc = (wd - ch * KC < KC) ? wd - ch * KC : KC;
+        if (nchunk > 1 || g == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int k = 0; k < kc; ++k) {
+            const int64_t e = base + (int64_t)64 * (ch * KC + k) + lane;
+            mc[k * 64 + lane] = __builtin_nontemporal_load(sl_col + e);
+            m1[k * 64 + lane] = __builtin_nontemporal_load(v1 + e);
+            m2[k * 64 + lane] = __builtin_nontemporal_load(v2 + e);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        const int rl0 = g * U * RS + grp;
+        switch (kc) {
+          case 8: spmm_sell_accum2<LG, U, 8>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 7: spmm_sell_accum2<LG, U, 7>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 6: spmm_sell_accum2<LG, U, 6>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 5: spmm_sell_accum2<LG, U, 5>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 4: spmm_sell_accum2<LG, U, 4>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 3: spmm_sell_accum2<LG, U, 3>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 2: spmm_sell_accum2<LG, U, 2>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          case 1: spmm_sell_accum2<LG, U, 1>(mc, m1, m2, rl0, Xq, ldx, acc1, acc2); break;
+          default: break;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
+        if (r >= n) continue;
+        __builtin_nontemporal_store(acc1[u], reinterpret_cast<d2*>(Y1 + r * ldy + 2 * q));
+        __builtin_nontemporal_store(acc2[u], reinterpret_cast<d2*>(Y2 + r * ldy + 2 * q));
+      }
+    }
+  }
+}
+bool spmm_dual_available(const Csr& a, int m) {
+  if (spmv_kind() != 1 || a.vec_lpr > 0 || a.nlong > 0 || !a.sl_ptr || !a.xcd_ptr || sell_wide_mm(a)) return false;
+  return m == 16 || m == 32 || m == 64;
+}
+void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* Y1, double* Y2, int ldy,
+               int m) {
+  if (a.n == 0) return;
+  if (!spmm_dual_available(a, m) || (ldx & 1) || (ldy & 1) || !aligned16(X) || !aligned16(Y1) || !aligned16(Y2))
+    throw std::runtime_error("spmm_dual: operands not on the sliced path");
+  ProfScope prof(PROF_SPMM, a.fine && m >= 16, (double)a.nnz * 20.0 + (double)a.n * 4.0 + 24.0 * m * (double)a.n,
+                 4.0 * (double)a.nnz * m);
+  int wpx = g_spmm_wpx < 0 ? 64 : (g_spmm_wpx == 0 ? 64 : g_spmm_wpx);
+  const int need = (a.nslice + 31) / 32;
+  if (wpx > need) wpx = need < 1 ? 1 : need;
+#define DUAL(L)                                                                                                                hipLaunchKernelGGL((k_spmm_sell_dual<L, 2>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, v1, v2, a.n, a.sched,                      a.xcd_ptr, X, ldx, Y1, Y2, ldy)
+  if (m == 16) DUAL(8);
+  else if (m == 32) DUAL(16);
+  else DUAL(32);
+#undef DUAL
+}
+// values of b laid out on the sliced pattern of a: out[e] = b(r, a.sl_col[e]) for the stored entries of row r of a, 0 for a's
+// entries b lacks and for the padding; *missing counts the entries of b that a's pattern does not hold
+__global__ __launch_bounds__(256) void k_sell_values_on(int n, int ns, const int64_t* __restrict__ sl_ptr,
+                                                        const int* __restrict__ sl_col, const int* __restrict__ arp,
+                                                        const int* __restrict__ brp, const int* __restrict__ bcol,
+                                                        const double* __restrict__ bval, double* __restrict__ out,
+                                                        int* __restrict__ missing) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= ns) return;
+  const int l = threadIdx.x & 63;
+  const int r = 64 * s + l;
+  const int64_t base = sl_ptr[s];
+  const int wd = (int)((sl_ptr[s + 1] - base) >> 6);
+  const int la = r < n ? arp[r + 1] - arp[r] : 0;
+  const int b0 = r < n ? brp[r] : 0, b1 = r < n ? brp[r + 1] : 0;
+  int found = 0;
+  for (int k = 0; k < wd; ++k) {
+    const int64_t e = base + (int64_t)64 * k + l;
+    double v = 0.0;
+    if (k < la) {
+      const int c = sl_col[e];
+      for (int t = b0; t < b1; ++t)
+        if (bcol[t] == c) { v = bval[t]; ++found; break; }
+    }
+    out[e] = v;
+  }
+  if (found != b1 - b0) atomicAdd(missing, 1);
+}
+double* sell_values_on(const Csr& a, const Csr& b) {
+  if (spmv_kind() != 1 || a.nlong > 0 || a.vec_lpr > 0 || !a.sl_ptr || a.n != b.n || a.nslice == 0) return nullptr;
+  double* out = (double*)alloc(sizeof(double) * (size_t)std::max<int64_t>(1, a.sl_nnz));
+  int* dmiss = (int*)alloc(sizeof(int));
+  hipLaunchKernelGGL(k_sell_values_on, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.n, a.nslice, a.sl_ptr, a.sl_col,
+                     a.rowptr, b.rowptr, b.col, b.val, out, dmiss);
+  int h = 0;
+  d2h(&h, dmiss, sizeof(int));
+  dfree(dmiss);
+  if (h) {            // b has entries outside a's pattern: no shared layout
+    dfree(out);
+    return nullptr;
+  }
+  return out;
+}
+
 static void spmm_ld(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                     const double* post) {
   if (a.n == 0 || m == 0) return;

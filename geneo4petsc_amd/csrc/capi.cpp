@@ -615,6 +615,20 @@ PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X, double* Y, 
 }
 
 // the same single-vector launches reading the single-precision companion of the matrix (built on first use); epi 0: Y = A X
+// Y1 = B X and Y2 = A X in one pass over X, B laid out on A's sliced pattern (bk::sell_values_on + bk::spmm_dual: LOBPCG's
+// A W / B W pass).  Returns 2 when pattern(B) is not contained in pattern(A) or A is not on the sliced path.
+PetscErrorCode GeneoSpmmDualTest(GeneoSpmv a, GeneoSpmv b, const double* X, int ldx, double* Y1, double* Y2, int ldy, int m) {
+  if (!a || !b) return 1;
+  GUARD_BEGIN
+  if (!bk::spmm_dual_available(a->a, m)) return 2;
+  double* v = bk::sell_values_on(a->a, b->a);
+  if (!v) return 2;
+  bk::spmm_dual(a->a, v, a->a.sl_val, X, ldx, Y1, Y2, ldy, m);
+  bk::sync();
+  bk::dfree(v);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
 PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X, double* Y, const double* B, double* Z,
                                     const double* dinv, double w) {
   if (!h) return 1;

@@ -1814,8 +1814,13 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       // unless A X / B X have just been refreshed
       if (!have_R || refreshed) bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);
       precondition();
-      applyA(W, AS + 2 * m);
-      applyB(W, BS + 2 * m);
+      if (P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m)) {    // A W and B W in one pass over W
+        bk::spmm_dual(*P.dual_pat, P.dual_vA, P.dual_vB, W, p3, AS + 2 * m, BS + 2 * m, p3, m);
+        info.eig_spmm += 2;
+      } else {
+        applyA(W, AS + 2 * m);
+        applyB(W, BS + 2 * m);
+      }
       if (!with_gram) return;
       if (reduced) {       // (A W)^T [X P W] and (B W)^T [X P W]: the W rows of the two Gram matrices, one pass over S
         bk::gram2(ch, AS + 2 * m, p3, m, BS + 2 * m, p3, m, S, p3, p3, dGW);
@@ -2068,7 +2073,14 @@ int PC::eigen_lobpcg() {
   // B = D A_Dir D (geneo.cpp:1243-1247, MatDiagonalScale on a copy) as a values-only copy sharing A_Dir's index
   // arrays: the block products with B then run without the two scaling gathers per entry
   bk::Csr dirBD = bk::csr_scaled_alias(dirB, d_D, d_D, false);
+  // GenEO-1: the pattern of A_Dir contains that of A_Neu (A_Dir = R A R^T holds every coupling among the subdomain's
+  // nodes, A_Neu those of the subdomain's own elements), so A_Neu can ride on A_Dir's sliced layout next to D A_Dir D and
+  // LOBPCG computes A W and B W in ONE pass over W (bk::spmm_dual).  nullptr (not contained / not on the sliced path):
+  // two products as before.
+  double* neu_on_dir = (!g2 && !getenv("GENEO_LOBPCG_NO_DUAL")) ? bk::sell_values_on(dirB, neuL) : nullptr;
   auto release = [&]() {
+    if (neu_on_dir) bk::dfree(neu_on_dir);
+    neu_on_dir = nullptr;
     bk::csr_free(dirBD);
     if (own_dirB) bk::csr_free(dirB);
   };
@@ -2208,6 +2220,11 @@ int PC::eigen_lobpcg() {
   {
     EigProblem pt{&neuL, nullptr, g2 ? &dirL : &dirBD, nullptr, (opt.els2_pc == "amg") ? amgN : nullptr,
                   d_dinvN, cheb_lmax, nev_try, "tau"};
+    if (neu_on_dir && dirBD.sl_val) {
+      pt.dual_pat = &dirB;
+      pt.dual_vA = neu_on_dir;
+      pt.dual_vB = dirBD.sl_val;
+    }
     if (opt.check)
       if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release_all(); return rc; }
     if (int rc = solve_grow(pt, false, stT)) { release_all(); return rc; }

@@ -193,6 +193,9 @@ class PC {
     const int* locked_cols = nullptr;     // per subdomain: columns locked so far (bounds the pairs that can still be asked for)
     int seed_off = 0;
     double tol = 0.0;                     // > 0: convergence tolerance of this solve instead of -els2_eps_tol
+    // A and B on ONE sliced pattern (bk::spmm_dual): A W and B W of an iteration in one pass over W
+    const bk::Csr* dual_pat = nullptr;
+    const double *dual_vA = nullptr, *dual_vB = nullptr;
   };
   int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
   int eig_targets(int* nev_try) const;

@@ -312,6 +312,10 @@ PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double*
 /* the single-vector launches (m = 1; epi 0: Y = A X) reading the matrix's single-precision companion -- float values,
  * 16-bit column offsets per 64-row slice (32-bit columns when a slice spans more than 65535), FP64 arithmetic: what the V-cycle of the local solves streams
  * (-dls1_amg_precision single).  Error when the matrix has no such companion. */
+/* Y1 = B X, Y2 = A X in ONE pass over X with B laid out on A's sliced pattern (LOBPCG's A W / B W pass); 2 = pattern(B)
+ * not contained in pattern(A) or A not on the sliced path */
+PetscErrorCode GeneoSpmmDualTest(GeneoSpmv a, GeneoSpmv b, const double* X_dev, int ldx, double* Y1_dev, double* Y2_dev,
+                                 int ldy, int m);
 PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, const double* B_dev,
                                     double* Z_dev, const double* dinv_dev, double w);
 /* device sparse products of the multigrid set-up (test hook): op 0: C = A B, op 1: C = A^T; returns nnz(C), -1 when a

@@ -22,6 +22,11 @@ const char* name() { return "hostsim"; }
 void set_stream(void* s) { g_stream = s; }
 void* get_stream() { return g_stream; }
 void sync() {}
+double* sell_values_on(const Csr&, const Csr&) { return nullptr; }   // the serial backend has no shared-pattern product
+bool spmm_dual_available(const Csr&, int) { return false; }
+void spmm_dual(const Csr&, const double*, const double*, const double*, int, double*, double*, int, int) {
+  throw std::runtime_error("spmm_dual: not in the serial backend");
+}
 int device_count() { return 0; }
 int set_device(int) { return -1; }
 void side_stream_begin(void*, bool) {}

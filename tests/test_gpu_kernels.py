@@ -341,3 +341,36 @@ def test_fused_lobpcg_update(lib):
             np.testing.assert_allclose(out[rows, :64], src[rows] @ Cm[s], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(R[rows], mask[s] * ((AS[rows] @ Cm[s])[:, :32] - lam[s] * (BS[rows] @ Cm[s])[:, :32]),
                                    rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("m", [16, 32, 64])
+def test_spmm_dual_two_operators_one_pass(lib, m):
+    """bk::spmm_dual (LOBPCG's A W and B W in one pass over W): B's values laid out on A's sliced pattern (pattern(B)
+    contained in pattern(A): A_Neu inside A_Dir), both products bit-identical to the separate launches; a B with an entry
+    outside A's pattern is refused."""
+    import ctypes as C
+    from geneo4petsc_amd.pc import Spmv, DeviceVector
+    g = 64                              # 7-point pattern (slices 7 entries wide: the wave-per-slice kernels), random values
+    e = np.ones(g)
+    t = sp.diags([e[:-1], e, e[:-1]], [-1, 0, 1])
+    i3 = sp.identity(g)
+    a = (sp.kron(sp.kron(t, i3), i3) + sp.kron(sp.kron(i3, t), i3) + sp.kron(sp.kron(i3, i3), t)).tocsr()
+    a.sort_indices()
+    a.data = np.random.default_rng(7).random(a.nnz) - 0.5
+    n = a.shape[0]
+    keep = np.random.default_rng(8).random(a.nnz) < 0.8
+    b = a.copy()
+    b.data = np.where(keep, np.random.default_rng(9).random(a.nnz) - 0.5, 0.0)
+    b.eliminate_zeros()
+    ha, hb = Spmv(a, lib), Spmv(b, lib)
+    ld = 96
+    X = np.random.default_rng(10).random((n, ld)) - 0.5
+    xd = DeviceVector.from_host(lib, X.ravel())
+    y1, y2 = DeviceVector(lib, n * ld), DeviceVector(lib, n * ld)
+    assert lib.GeneoSpmmDualTest(ha.h, hb.h, xd.ptr, ld, y1.ptr, y2.ptr, ld, m) == 0
+    Y1 = y1.to_host().reshape(n, ld)[:, :m]
+    Y2 = y2.to_host().reshape(n, ld)[:, :m]
+    np.testing.assert_array_equal(Y2, ha.spmm(np.ascontiguousarray(X[:, :m])))
+    np.testing.assert_array_equal(Y1, hb.spmm(np.ascontiguousarray(X[:, :m])))
+    np.testing.assert_allclose(Y1, b @ X[:, :m], rtol=1e-12, atol=1e-13)
+    assert lib.GeneoSpmmDualTest(hb.h, ha.h, xd.ptr, ld, y1.ptr, y2.ptr, ld, m) == 2      # A is not inside B's pattern
