@@ -572,6 +572,8 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     return std::chrono::duration<double>(b - a).count();
   };
   HostCsr Acur;                       // host copy of the current level's matrix (levels >= 1)
+  AmgLevelHostPart hp_next;           // host part of the level to come, when the helper thread of the last one made it
+  bool have_next = false;
   std::vector<int> so = suboff;
   double nnz0 = 0.0, nnzt = 0.0;
   bk::Csr Adev = *fine_dev;
@@ -590,7 +592,14 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     L.own_A = own;
     // host part of the level (diagonal, Gershgorin bound, aggregates): level 0 may have been computed early by the caller
     AmgLevelHostPart hp_own;
-    if (!(l == 0 && level0)) hp_own = amg_level_host_part(Ah, so, prm, l);
+    if (l == 0 && level0) {
+      // computed early by the caller
+    } else if (have_next) {
+      hp_own = std::move(hp_next);        // computed by the previous level's helper thread, behind its device work
+      have_next = false;
+    } else {
+      hp_own = amg_level_host_part(Ah, so, prm, l);
+    }
     const AmgLevelHostPart& hp = (l == 0 && level0) ? *level0 : hp_own;
     const std::vector<double>& dinv = hp.dinv;
     L.rho = hp.rho;
@@ -650,14 +659,19 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     next.val.resize((size_t)Ac.nnz);
     std::exception_ptr dl_err;
     void* parent = bk::get_stream();
+    const int next_level = l + 1;
     std::thread dl([&]() {
       try {
         bk::side_stream_begin(parent, true);
         bk::csr_download(Ac, next.rowptr.data(), next.col.data(), next.val.data());
+        bk::side_stream_end();
+        // ... and the host part of the NEXT level (diagonal, aggregates) while the parent is still busy with this one
+        hp_next = amg_level_host_part(next, csub, prm, next_level);
+        have_next = true;
       } catch (...) {
+        bk::side_stream_end();
         dl_err = std::current_exception();
       }
-      bk::side_stream_end();
     });
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } dl_join{dl};
     bk::csr_finish(P);
