@@ -494,10 +494,11 @@ void PC::make_robin(Sub& s, HostCsr& out) const {
   }
 }
 
-static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
-                              const int* colmap /*nullable: L -> ext*/) {
+// `b` may come in with the arrays of an earlier set-up: they are reused (same sizes: no reallocation, no zero fill, no
+// page faults -- a third of the 0.035 s this copy costs at 126^3)
+static void make_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
+                           const int* colmap /*nullable: L -> ext*/, HostCsr& b) {
   const int ns = (int)mats.size();
-  HostCsr b;
   b.n = suboff[ns];
   std::vector<size_t> nzoff(ns + 1, 0);
   for (int s = 0; s < ns; ++s) nzoff[s + 1] = nzoff[s] + mats[s]->val.size();
@@ -507,7 +508,7 @@ static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std
     if (big) tv = std::thread([&]() { b.val.resize(nzoff[ns]); });
     else b.val.resize(nzoff[ns]);
     b.col.resize(nzoff[ns]);
-    b.rowptr.assign(b.n + 1, 0);
+    b.rowptr.resize((size_t)b.n + 1);
     if (tv.joinable()) tv.join();
   }
   // Row ranges of about equal size over all the matrices: with ONE subdomain per rank (the N > 1 layout of bench.py) a
@@ -529,6 +530,7 @@ static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std
       r0 = r1;
     }
   }
+  b.rowptr[0] = 0;
   auto fill = [&](const Task& t) {
     const HostCsr& m = *mats[t.s];
     const int off = suboff[t.s];
@@ -552,12 +554,13 @@ static HostCsr make_blockdiag(const std::vector<const HostCsr*>& mats, const std
   } else {
     for (const Task& t : tasks) fill(t);
   }
-  return b;
 }
 static bk::Csr upload_host(const HostCsr& b) { return bk::csr_upload(b.n, b.rowptr.data(), b.col.data(), b.val.data()); }
 static bk::Csr upload_blockdiag(const std::vector<const HostCsr*>& mats, const std::vector<int>& suboff,
                                 const int* colmap /*nullable: L -> ext*/) {
-  return upload_host(make_blockdiag(mats, suboff, colmap));
+  HostCsr b;
+  make_blockdiag(mats, suboff, colmap, b);
+  return upload_host(b);
 }
 
 static AmgParams amg_params(const Options& opt) {
@@ -630,7 +633,8 @@ int PC::setup(const double* b_dev) {
   // With ONE subdomain on this rank (the N > 1 layout of bench.py: a 6.5 M-row block) the block-diagonal matrices ARE the
   // subdomain's: they are used where they lie instead of being copied (0.085 s per matrix at that size).
   const bool single_block = (ns == 1);
-  HostCsr h_dirL_own, h_neuL_own;
+  HostCsr& h_dirL_own = host_dir_cache;      // kept between set-ups of this PC (released in PCDestroy / when sizes change)
+  HostCsr& h_neuL_own = host_neu_cache;
   std::exception_ptr dir_err;      // a bad_alloc on the thread must come back as an error code, not std::terminate
   // The level-1 matrix is assembled AND uploaded (with its 16-bit column offsets / float values: the FP64 SpMV of the
   // local solves then reads 10 bytes per entry instead of 12, the level-1 hierarchy borrows the companion) by its own
@@ -638,7 +642,7 @@ int PC::setup(const double* b_dev) {
   // streams into pinned memory.
   std::thread dir_thread([&]() {
     try {
-      if (!single_block) h_dirL_own = make_blockdiag(lvl1, suboff, nullptr);
+      if (!single_block) make_blockdiag(lvl1, suboff, nullptr, h_dirL_own);
       bk::side_stream_begin();
       dirL = upload_host(single_block ? *lvl1[0] : h_dirL_own);
       dirL.fine = true;
@@ -650,7 +654,7 @@ int PC::setup(const double* b_dev) {
     }
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } dir_joiner{dir_thread};
-  if (!single_block) h_neuL_own = make_blockdiag(neu, suboff, nullptr);
+  if (!single_block) make_blockdiag(neu, suboff, nullptr, h_neuL_own);
   const HostCsr& h_neuL = single_block ? *neu[0] : h_neuL_own;
   const bool want1 = (opt.dls1_pc == "amg");
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
@@ -694,8 +698,7 @@ int PC::setup(const double* b_dev) {
   if (want1) {
     if (single_block) pend1->matp = lvl1[0];        // subs[0].a_dir or the Robin matrix of this set-up: both outlive the thread
     else {
-      pend1->mat_own = std::move(h_dirL_own);
-      pend1->matp = &pend1->mat_own;
+      pend1->matp = &h_dirL_own;                   // the PC's own copy: outlives the thread
     }
     if (early0 && !getenv("GENEO_AMG1_HOST")) {
       Amg1Pending* pp = pend1.get();

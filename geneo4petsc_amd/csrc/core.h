@@ -169,6 +169,7 @@ class PC {
   int cg_long_len = 0;         // length of the first chunk of a local solve once the first solve of this set-up is known (0: not yet, -1: never)
   bool cg_graph_failed = false;
   long long cg_chunks = 0;     // chunks issued so far (sampling of direct launches while the in-situ timer runs)
+  HostCsr host_neu_cache, host_dir_cache;   // block-diagonal host copies of A_Neu / the level-1 matrix, reused by the next set-up
   AmgDevice* amg1 = nullptr;   // hierarchy of the level-1 (Dirichlet / Robin) block-diagonal matrix (local solves)
   AmgDevice* amgN = nullptr;   // hierarchy of the Neumann block-diagonal matrix (LOBPCG preconditioner)
 
