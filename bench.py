@@ -503,6 +503,9 @@ def main():
     from geneo4petsc_amd import _lib
     from geneo4petsc_amd.pc import GenEOPC, DeviceVector
     lib = _lib.load()
+    # the library's own threads (side-stream set-up, upload helpers) are bound to this device, not to GPU 0
+    if lib.GeneoSetDevice(local_rank) != local_rank:
+        raise SystemExit("bench.py: rank %d could not select GPU %d" % (rank, local_rank))
     lib.GeneoSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     t_prep = time.perf_counter()

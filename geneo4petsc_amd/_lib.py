@@ -121,6 +121,8 @@ SYMBOLS = {
     "GeneoPartGraphKway": (C.c_int, [C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p]),
     "GeneoDeviceCount": (C.c_int, []),
     "GeneoSetDevice": (C.c_int, [C.c_int]),
+    "GeneoCurrentDevice": (C.c_int, []),
+    "GeneoThreadDeviceCheck": (C.c_int, []),
     "GeneoAllocCacheRelease": (None, []),
     "GeneoDeviceAlloc": (C.c_void_p, [C.c_size_t]),
     "GeneoDeviceFree": (None, [C.c_void_p]),

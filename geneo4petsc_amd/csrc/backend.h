@@ -31,6 +31,8 @@ void side_stream_end();
 
 int   device_count();                     // GPUs visible to this process
 int   set_device(int ordinal);            // binds the calling thread's (and the library's) work to that GPU; returns it, -1 on failure
+int   current_device();                  // the device the library's threads are bound to (-1: not configured yet)
+int   thread_device_check();             // test hook: device of a freshly started library thread after the binding (see bind_thread)
 void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
 void  dfree(void* p);
 void  alloc_cache_release();   // hipFree every block the caching allocator holds (backend_hip.hip: alloc)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -48,7 +49,33 @@ static thread_local hipStream_t t_stream_side = nullptr;
 static thread_local bool t_side = false;
 static thread_local bool g_capturing = false;   // between graph_capture_begin and graph_capture_end (per thread)
 static thread_local hipStream_t g_capture_stream = nullptr;   // launches of a capturing thread are recorded here
-static inline hipStream_t stream_cur() { return g_capturing ? g_capture_stream : (t_side ? t_stream_side : g_stream_main); }
+// The HIP "current device" is a property of the HOST THREAD and a new thread starts on device 0: on a node with several
+// GPUs visible to the process (one rank per GPU under torchrun, LOCAL_RANK = 1 .. 7) a thread started by the library --
+// the level-1 set-up on its side stream, the upload / download helpers -- would create its stream, allocate and launch on
+// GPU 0.  The library therefore remembers the device of the thread that configured it (GeneoSetDevice, GeneoSetStream, or
+// the first allocation) and every other thread is bound to that device before its first HIP call: bind_thread() sits in
+// stream_cur(), which every launch and copy goes through, and in the calls that take no stream.
+static std::atomic<int> g_device{-1};
+static thread_local bool t_dev_bound = false;
+static inline void bind_thread() {
+  if (t_dev_bound) return;
+  t_dev_bound = true;
+  const int want = g_device.load(std::memory_order_acquire);
+  if (want < 0) {                 // first HIP call of the library: this thread's device is the library's
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess) g_device.store(d, std::memory_order_release);
+    else (void)hipGetLastError();
+  } else {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d != want) {
+      if (hipSetDevice(want) != hipSuccess) throw std::runtime_error("geneo: hipSetDevice failed on a library thread");
+    }
+  }
+}
+static inline hipStream_t stream_cur() {
+  bind_thread();
+  return g_capturing ? g_capture_stream : (t_side ? t_stream_side : g_stream_main);
+}
 #define g_stream (stream_cur())
 static bool g_no_mfma = false;
 static bool g_init = false;
@@ -66,9 +93,15 @@ void set_stream(void* s) {
   // ordering between two main streams otherwise)
   if ((hipStream_t)s != g_stream_main) (void)hipStreamSynchronize(g_stream_main);
   g_stream_main = (hipStream_t)s;
+  // the host hands over a stream of ITS current device: that is the device every library thread works on
+  int d = 0;
+  if (hipGetDevice(&d) == hipSuccess) g_device.store(d, std::memory_order_release);
+  else (void)hipGetLastError();
+  t_dev_bound = true;
 }
 void side_stream_begin(void* after, bool use_after) {
   if (t_side) return;
+  bind_thread();
   if (!t_stream_side) HIPCHK(hipStreamCreateWithFlags(&t_stream_side, hipStreamNonBlocking));
   // ordered behind everything the parent stream (default: the main stream) has been given so far -- the matrices this
   // thread is going to read
@@ -99,7 +132,25 @@ int set_device(int ordinal) {
   if (n <= 0 || ordinal < 0) return -1;
   const int d = ordinal % n;
   if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  g_device.store(d, std::memory_order_release);
+  t_dev_bound = true;
   return d;
+}
+int current_device() { return g_device.load(std::memory_order_acquire); }
+// test hook: the device a thread started by the library ends up on (after the binding every HIP path goes through)
+int thread_device_check() {
+  int got = -2;
+  std::thread t([&]() {
+    try {
+      (void)stream_cur();
+      int d = -1;
+      if (hipGetDevice(&d) == hipSuccess) got = d;
+    } catch (...) {
+      got = -3;
+    }
+  });
+  t.join();
+  return got;
 }
 static double g_alloc_s = 0.0, g_free_s = 0.0;
 static long long g_alloc_n = 0;
@@ -131,6 +182,7 @@ static inline size_t alloc_round(size_t bytes) {
   return (bytes + g - 1) / g * g;
 }
 void alloc_cache_release() {
+  bind_thread();
   std::lock_guard<std::mutex> lk(g_alloc_mu);
   if (g_cache.empty()) return;
   auto t0 = std::chrono::high_resolution_clock::now();
@@ -145,6 +197,7 @@ void alloc_cache_release() {
 }
 void* alloc(size_t bytes) {
   lazy_init();
+  bind_thread();
   void* p = nullptr;
   if (bytes == 0) bytes = 8;
   const size_t sz = alloc_cache_on() ? alloc_round(bytes) : bytes;
@@ -184,6 +237,7 @@ void* alloc(size_t bytes) {
 }
 void dfree(void* p) {
   if (!p) return;
+  bind_thread();
   if (alloc_cache_on()) {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     auto it = g_live.find(p);
@@ -228,6 +282,7 @@ static std::mutex g_stage_mu;
 static std::condition_variable g_stage_cv;
 static StageSet* stage_acquire() {
   if (getenv("GENEO_NO_PINNED_STAGING")) return nullptr;
+  bind_thread();
   std::unique_lock<std::mutex> lk(g_stage_mu);
   for (;;) {
     bool any_usable = false;
@@ -477,10 +532,21 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
   a.rowptr = (int*)alloc(sizeof(int) * (size_t)(n + 1));
   a.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)a.nnz));
   a.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  static const bool dbg = getenv("GENEO_DEBUG") != nullptr;
+  auto t0 = std::chrono::high_resolution_clock::now();
   h2d(a.rowptr, h_rowptr, sizeof(int) * (size_t)(n + 1));
   h2d(a.col, h_col, sizeof(int) * (size_t)a.nnz);
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
+  auto t1 = std::chrono::high_resolution_clock::now();
   finish_layout(a, h_rowptr, h_col);
+  if (dbg && a.nnz > 4000000) {
+    HIPCHK(hipStreamSynchronize(g_stream));
+    auto t2 = std::chrono::high_resolution_clock::now();
+    fprintf(stderr, "[upload] n %d nnz %lld: copies %.4f s (%.1f GB/s), layouts %.4f s\n", n, (long long)a.nnz,
+            std::chrono::duration<double>(t1 - t0).count(),
+            (12.0 * a.nnz + 4.0 * n) / std::chrono::duration<double>(t1 - t0).count() / 1e9,
+            std::chrono::duration<double>(t2 - t1).count());
+  }
   return a;
 }
 // SpMV layouts (LDS row blocks, 64-row slices, long-row list, lanes-per-row choice) of a matrix whose CSR arrays are
@@ -498,32 +564,58 @@ static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_c
   static const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto)
   if (mode && !strcmp(mode, "natural")) return {};
   if (nslice < 4 * TILE) return {};
+  // Sampling: 4 rows per slice, two dependent cache misses each (row pointer, columns) -- latency-bound on one host thread
+  // (25-45 ms for the 102 000 slices of a 6.5 M-row block), so the slices are sampled in ranges on up to 8 threads; the
+  // per-slice lists are concatenated in slice order, i.e. the result does not depend on the number of threads.
   std::vector<int> adj_ptr((size_t)nslice + 1, 0), adj;
-  adj.reserve((size_t)nslice * 8);
-  int far = 0;
-  for (int s = 0; s < nslice; ++s) {
-    int loc[64];
-    int cnt = 0;
-    const int r0 = 64 * s, r1 = std::min(n, r0 + 64);
-    const int probe[4] = {r0, r0 + 21, r0 + 42, r1 - 1};
-    for (int t = 0; t < 4; ++t) {
-      const int r = std::min(probe[t], r1 - 1);
-      for (int k = h_rowptr[r]; k < h_rowptr[r + 1] && cnt < 60; ++k) {
-        const int o = h_col[k] >> 6;
-        if (o == s || o >= nslice) continue;
-        bool seen = false;
-        for (int i = 0; i < cnt; ++i) seen = seen || loc[i] == o;
-        if (!seen) loc[cnt++] = o;
+  constexpr int CAP = 60;
+  const int nth = std::max(1, std::min(8, nslice / 4096));
+  std::vector<std::vector<int>> part_adj(nth);
+  std::vector<int> part_far(nth, 0);
+  std::vector<int> cnts((size_t)nslice, 0);
+  auto sample = [&](int t) {
+    const int s0 = (int)((int64_t)nslice * t / nth), s1 = (int)((int64_t)nslice * (t + 1) / nth);
+    std::vector<int>& out = part_adj[t];
+    out.reserve((size_t)(s1 - s0) * 8);
+    int far_t = 0;
+    for (int s = s0; s < s1; ++s) {
+      int loc[64];
+      int cnt = 0;
+      const int r0 = 64 * s, r1 = std::min(n, r0 + 64);
+      const int probe[4] = {r0, r0 + 21, r0 + 42, r1 - 1};
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int r = std::min(probe[t4], r1 - 1);
+        for (int k = h_rowptr[r]; k < h_rowptr[r + 1] && cnt < CAP; ++k) {
+          const int o = h_col[k] >> 6;
+          if (o == s || o >= nslice) continue;
+          bool seen = false;
+          for (int i = 0; i < cnt; ++i) seen = seen || loc[i] == o;
+          if (!seen) loc[cnt++] = o;
+        }
       }
+      for (int i = 0; i < cnt; ++i) {
+        out.push_back(loc[i]);
+        far_t = std::max(far_t, std::abs(loc[i] - s));
+      }
+      cnts[s] = cnt;
     }
-    for (int i = 0; i < cnt; ++i) {
-      adj.push_back(loc[i]);
-      far = std::max(far, std::abs(loc[i] - s));
-    }
-    adj_ptr[s + 1] = (int)adj.size();
+    part_far[t] = far_t;
+  };
+  if (nth > 1) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(sample, t);
+    sample(0);
+    for (auto& x : th) x.join();
+  } else {
+    sample(0);
   }
+  int far = 0;
+  for (int t = 0; t < nth; ++t) far = std::max(far, part_far[t]);
+  for (int s = 0; s < nslice; ++s) adj_ptr[s + 1] = adj_ptr[s] + cnts[s];
   // natural order keeps the far neighbours in flight while they are within a fraction of the slices a group holds
   if (!(mode && !strcmp(mode, "blob")) && far < TILE / 4) return {};
+  adj.reserve((size_t)adj_ptr[nslice]);
+  for (int t = 0; t < nth; ++t) adj.insert(adj.end(), part_adj[t].begin(), part_adj[t].end());
   std::vector<int> order;
   order.reserve(nslice);
   std::vector<char> seen((size_t)nslice, 0);
@@ -553,6 +645,15 @@ static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_c
 
 static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
   const int n = a.n;
+  static const bool dbg_l = getenv("GENEO_DEBUG") != nullptr;
+  auto tl0 = std::chrono::high_resolution_clock::now();
+  auto lapl = [&](const char* what) {
+    if (!dbg_l || a.nnz < 4000000) return;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    auto t = std::chrono::high_resolution_clock::now();
+    fprintf(stderr, "[layout] %-22s %.4f s\n", what, std::chrono::duration<double>(t - tl0).count());
+    tl0 = t;
+  };
   int maxrow = 0;
   std::vector<int> longr;
   const int long_len = SELL_LONG;
@@ -562,6 +663,7 @@ static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
     if (len > long_len) longr.push_back(i);
   }
   a.max_row = maxrow;
+  lapl("row lengths (host)");
   if (spmv_kind() == 0) {
     // row blocks of the LDS kernel: as many consecutive rows as fit SPMV_TILE nnz and SPMV_ROWS rows;
     // a row longer than the tile gets a block of its own (long-row path)
@@ -602,9 +704,11 @@ static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
     a.sl_col = (int*)alloc(sizeof(int) * (size_t)std::max<int64_t>(1, sp[ns]));
     a.sl_val = (double*)alloc(sizeof(double) * (size_t)std::max<int64_t>(1, sp[ns]));
     h2d(a.sl_ptr, sp.data(), sizeof(int64_t) * (ns + 1));
+    lapl("slice widths + scan");
     if (ns > 0)
       hipLaunchKernelGGL(k_sell_fill, dim3((ns + 3) / 4), dim3(256), 0, g_stream, a.rowptr, a.col, a.val, n, ns,
                          a.sl_ptr, a.sl_col, a.sl_val, long_len);
+    lapl("slice fill");
     {   // traversal of the sliced SpMM: eight contiguous ranges of the slice schedule, one per XCD group
       int xp[9];
       for (int g = 0; g <= 8; ++g) xp[g] = (int)(((int64_t)ns * g) / 8);
@@ -618,6 +722,7 @@ static void finish_layout(Csr& a, const int* h_rowptr, const int* h_col) {
         }
       }
     }
+    lapl("blob schedule");
     a.nlong = (int)longr.size();
     // Long or ragged rows (restriction operators, coarse Galerkin matrices): one lane group per row reads the
     // row coalesced and reduces with shuffles; the slices would pad every 64-row slice to its longest row.

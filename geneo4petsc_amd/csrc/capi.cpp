@@ -456,6 +456,8 @@ PetscErrorCode GeneoSetStream(void* s) {
 }
 int GeneoDeviceCount(void) { return bk::device_count(); }
 int GeneoSetDevice(int local_rank) { return bk::set_device(local_rank); }
+int GeneoCurrentDevice(void) { return bk::current_device(); }
+int GeneoThreadDeviceCheck(void) { return bk::thread_device_check(); }
 void GeneoAllocCacheRelease(void) { bk::alloc_cache_release(); }
 void* GeneoDeviceAlloc(size_t bytes) {
   try {

@@ -1766,6 +1766,12 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       for (int j = 0; j < m; ++j) nl += locked[(size_t)s * m + j] ? 1 : 0;
       fprintf(stderr, " %d", nl);
     }
+    fprintf(stderr, " | prefix");
+    for (int s = 0; s < ns; ++s) {
+      int k = 0;
+      while (k < m && (locked[(size_t)s * m + k] || frozen[s])) ++k;
+      fprintf(stderr, " %d", k);
+    }
     fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[std::max(1, nev_s[0]) - 1], P.amg ? "amg" : "cheb");
   };
   for (it = 0; it <= opt.eps_max_it; ++it) {

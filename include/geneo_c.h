@@ -264,6 +264,12 @@ PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to 
  * as adapters/geneo_petsc_adapter.cpp does -- or give every rank its own HIP_VISIBLE_DEVICES and skip the call. */
 int GeneoDeviceCount(void);
 int GeneoSetDevice(int local_rank);
+/* The HIP current device belongs to the host THREAD: the library binds every thread it starts (side-stream set-up, upload
+ * helpers) to the device of the thread that configured it (GeneoSetDevice, GeneoSetStream or the first allocation).
+ * GeneoCurrentDevice: that device (-1 before the first call).  GeneoThreadDeviceCheck (test hook): starts a thread the
+ * way the library does and returns the device it ends up on -- equal to GeneoCurrentDevice() or the binding is broken. */
+int GeneoCurrentDevice(void);
+int GeneoThreadDeviceCheck(void);
 /* hipFree every device block the library's caching allocator is holding (it keeps freed blocks for the next set-up, up
  * to GENEO_ALLOC_CACHE_GB, default 96): call it when another allocator of the process needs the memory. */
 void GeneoAllocCacheRelease(void);

@@ -29,6 +29,8 @@ void spmm_dual(const Csr&, const double*, const double*, const double*, int, dou
 }
 int device_count() { return 0; }
 int set_device(int) { return -1; }
+int current_device() { return -1; }
+int thread_device_check() { return -1; }
 void side_stream_begin(void*, bool) {}
 void side_stream_end() {}
 

@@ -374,3 +374,21 @@ def test_spmm_dual_two_operators_one_pass(lib, m):
     np.testing.assert_array_equal(Y1, hb.spmm(np.ascontiguousarray(X[:, :m])))
     np.testing.assert_allclose(Y1, b @ X[:, :m], rtol=1e-12, atol=1e-13)
     assert lib.GeneoSpmmDualTest(hb.h, ha.h, xd.ptr, ld, y1.ptr, y2.ptr, ld, m) == 2      # A is not inside B's pattern
+
+
+def test_library_threads_run_on_the_librarys_device(lib):
+    """The HIP current device is per host thread and a new thread starts on device 0: threads the library starts (the
+    level-1 set-up on its side stream, upload helpers) must be bound to the device of the thread that configured the
+    library -- on a node with several visible GPUs rank r > 0 would otherwise allocate and launch on GPU 0.  With one
+    visible GPU this is a sanity check of the hook; with more, the LAST device is selected first so that a thread left on
+    device 0 is caught."""
+    nd = lib.GeneoDeviceCount()
+    assert nd >= 1
+    want = lib.GeneoSetDevice(nd - 1)
+    try:
+        assert want == nd - 1
+        assert lib.GeneoCurrentDevice() == want
+        assert lib.GeneoThreadDeviceCheck() == want
+    finally:
+        assert lib.GeneoSetDevice(0) == 0
+    assert lib.GeneoThreadDeviceCheck() == 0
