@@ -40,14 +40,16 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("lvl,ksp,parts", [("SRAS,1", "cg", (2, 1, 1)),        # one subdomain per rank: bench.py's N > 1 layout
-                                           ("RAS,H1", "gmres", (2, 2, 2))])      # four per rank, hybrid: every operator
-def test_cpp_rccl_transport_two_peers_matches_serial_oracle(tmp_path, lvl, ksp, parts):
+@pytest.mark.parametrize("lvl,ksp,parts,nproc", [
+    ("SRAS,1", "cg", (2, 1, 1), 2),        # one subdomain per rank: bench.py's N = 2 layout
+    ("RAS,H1", "gmres", (2, 2, 2), 2),     # four per rank, hybrid: every operator
+    ("SRAS,1", "cg", (2, 2, 1), 4)])       # bench.py's N = 4 layout: every rank has three peers in one ncclGroup
+def test_cpp_rccl_transport_two_peers_matches_serial_oracle(tmp_path, lvl, ksp, parts, nproc):
     standin = build_standin()
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", GENEO_WORKER_LIB="rccl_standin",
                GENEO_RCCL_LIBRARY=standin)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "gloo_worker.py"), out, lvl, ksp,
            ",".join(str(p) for p in parts)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
