@@ -131,6 +131,7 @@ SYMBOLS = {
     "GeneoDeviceSync": (C.c_int, []),
     "GeneoSelfTestMFMA": (C.c_int, []),
     "GeneoSetMFMA": (C.c_int, [C.c_int]),
+    "GeneoSetKernelVariant": (C.c_int, [C.c_char_p, C.c_int]),
     "GeneoTestAxpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int]),
     "GeneoSetSpmvKind": (C.c_int, [C.c_int]),
     "GeneoSpmvKernelName": (C.c_char_p, []),

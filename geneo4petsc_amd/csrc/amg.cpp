@@ -560,6 +560,54 @@ AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& 
   return h;
 }
 
+// Host arrays of the coarse matrices that build_on_device downloads, kept from one hierarchy to the next: a fresh
+// std::vector of the first coarse matrix (126^3: 10 M entries, 123 MB) costs 20 ms of page faults and zero fill on the
+// thread that sizes it -- the device sat idle for exactly that long in every set-up (kernel timeline, round 3).  Arrays
+// returned to the pool keep their size; taking one of the same size (the next set-up of the same problem) touches nothing.
+namespace {
+struct HostCsrPool {
+  std::mutex mu;
+  std::vector<HostCsr> parked;
+  static constexpr size_t MAX_PARKED = 12;
+  HostCsr take(int n, size_t nnz) {
+    HostCsr out;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int best = -1;
+      for (size_t i = 0; i < parked.size(); ++i) {
+        const HostCsr& h = parked[i];
+        if (h.col.size() == nnz && h.rowptr.size() == (size_t)n + 1) { best = (int)i; break; }     // same problem again
+        if (h.col.capacity() >= nnz && h.rowptr.capacity() >= (size_t)n + 1 &&
+            (best < 0 || h.col.capacity() < parked[best].col.capacity()))
+          best = (int)i;
+      }
+      if (best >= 0) {
+        out = std::move(parked[best]);
+        parked.erase(parked.begin() + best);
+      }
+    }
+    out.n = n;
+    out.rowptr.resize((size_t)n + 1);
+    out.col.resize(nnz);
+    out.val.resize(nnz);
+    return out;
+  }
+  void give(HostCsr&& h) {
+    if (h.col.capacity() < (1u << 16)) return;       // small ones are not worth keeping
+    std::lock_guard<std::mutex> lk(mu);
+    if (parked.size() >= MAX_PARKED) {               // drop the smallest
+      size_t k = 0;
+      for (size_t i = 1; i < parked.size(); ++i)
+        if (parked[i].col.capacity() < parked[k].col.capacity()) k = i;
+      if (parked[k].col.capacity() >= h.col.capacity()) return;
+      parked.erase(parked.begin() + k);
+    }
+    parked.push_back(std::move(h));
+  }
+};
+HostCsrPool g_host_csr_pool;
+}  // namespace
+
 bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff, const AmgParams& p, int max_m,
                                 const bk::Csr* fine_dev, const AmgLevelHostPart* level0) {
   free_all();
@@ -628,18 +676,12 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     }
     // ---- device: P0, A P0, P, R = P^T, A P, R A P
     const int n = Ah.n;
-    bk::Csr P0;
-    {
-      std::vector<int> rp(n + 1);
-      for (int i = 0; i <= n; ++i) rp[i] = i;
-      std::vector<double> ones(n, 1.0);
-      P0 = bk::csr_upload_raw(n, rp.data(), agg.data(), ones.data());
-    }
+    int* d_agg = (int*)bk::alloc(sizeof(int) * std::max(1, n));
+    bk::h2d(d_agg, agg.data(), sizeof(int) * n);
+    bk::Csr P0 = bk::csr_tentative_prolongator(n, d_agg);     // rows of one entry 1.0, made on the device
     bool ok = true;
     bk::Csr P = bk::spgemm(Adev, P0, nc, &ok);
-    if (!ok) { bk::csr_free(P0); bk::dfree(L.dinv); return abandon(); }
-    int* d_agg = (int*)bk::alloc(sizeof(int) * n);
-    bk::h2d(d_agg, agg.data(), sizeof(int) * n);
+    if (!ok) { bk::csr_free(P0); bk::dfree(d_agg); bk::dfree(L.dinv); return abandon(); }
     bk::smooth_prolongator(P, d_agg, L.dinv, 4.0 / (3.0 * L.rho));
     bk::dfree(d_agg);
     bk::csr_free(P0);
@@ -652,11 +694,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     // next level: its matrix on the host for the aggregation / diagonal / coarsest inverse.  The download runs on a
     // helper thread with its own stream (ordered behind the product that made Ac) while this one finishes the level:
     // SpMV layouts of P, R, Ac, the column-scaled copy and the post-smoothing matrix M.
-    HostCsr next;
-    next.n = nc;
-    next.rowptr.resize((size_t)nc + 1);
-    next.col.resize((size_t)Ac.nnz);
-    next.val.resize((size_t)Ac.nnz);
+    HostCsr next = g_host_csr_pool.take(nc, (size_t)Ac.nnz);
     std::exception_ptr dl_err;
     void* parent = bk::get_stream();
     const int next_level = l + 1;
@@ -690,11 +728,13 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     if (dbg)
       fprintf(stderr, "[amg/device] level n %d -> %d nnz %zu -> %zu | host diag+aggregation %.3f, device products %.3f, download %.3f s\n",
               n, nc, Ah.val.size(), next.val.size(), tsec(t_0, t_1), tsec(t_1, t_2), tsec(t_2, tnow()));
+    g_host_csr_pool.give(std::move(Acur));
     Acur = std::move(next);
     Adev = Ac;
     own = true;
     so = csub;
   }
+  g_host_csr_pool.give(std::move(Acur));
   opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;
   if (prm.single) make_single();
   return true;

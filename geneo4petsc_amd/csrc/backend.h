@@ -81,6 +81,9 @@ struct Csr {
 };
 Csr  csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val);
 Csr  csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h_val);   // CSR arrays only (no SpMV layouts)
+// tentative prolongator of an aggregation: one entry 1.0 per row in column agg[i] (agg_dev: n aggregate ids in HBM);
+// CSR arrays only, built on the device (the host used to fill and upload 16 bytes per row of iota and ones)
+Csr  csr_tentative_prolongator(int n, const int* agg_dev);
 void csr_free(Csr& a);
 // ---- sparse products on the device (multigrid set-up: Galerkin products without a host round trip) ----------------
 // C = A B (B has ncols_b columns) and A^T (A has ncols columns).  Columns come out sorted inside every row and
@@ -272,6 +275,8 @@ void z_rowmajor(const Chunks& c, const double* Z, const int64_t* zbase, const in
 void  set_spmv_kind(int kind);  // 0: LDS row-block kernel, 1: 64-row sliced kernel (default)
 const char* spmv_kernel_name();
 void  set_mfma(bool enable);   // false: run the plain-FMA twins of the MFMA kernels (validation)
+// validation switches between two device forms of the same arithmetic ("spgemm_fill_scan", "gram_flat"); false: unknown name
+bool  set_variant(const char* name, int value);
 int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as the kernels assume
 void* event_create();
 // device-to-host copy on a side stream as soon as `event` (recorded on the library stream) has completed: the library

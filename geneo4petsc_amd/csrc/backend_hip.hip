@@ -78,6 +78,8 @@ static inline hipStream_t stream_cur() {
 }
 #define g_stream (stream_cur())
 static bool g_no_mfma = false;
+static bool g_spgemm_fill_scan = getenv("GENEO_SPGEMM_SCAN_FILL") != nullptr;   // the owner-computes numeric pass of round 2
+static bool g_gram_flat = getenv("GENEO_GRAM_NO_FLAT") == nullptr;               // 16-byte streaming form of LOBPCG's Grams
 static bool g_init = false;
 
 static void lazy_init() {
@@ -525,6 +527,23 @@ Csr csr_upload_raw(int n, const int* h_rowptr, const int* h_col, const double* h
   h2d(a.val, h_val, sizeof(double) * (size_t)a.nnz);
   return a;
 }
+__global__ void k_iota_ones(int* __restrict__ rp, double* __restrict__ val, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+    rp[i] = i;
+    if (i < n) val[i] = 1.0;
+  }
+}
+Csr csr_tentative_prolongator(int n, const int* agg_dev) {
+  Csr a;
+  a.n = n;
+  a.nnz = n;
+  a.rowptr = (int*)alloc(sizeof(int) * (size_t)(n + 1));
+  a.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)n));
+  a.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)n));
+  hipLaunchKernelGGL(k_iota_ones, dim3(grid1d(n + 1, 256)), dim3(256), 0, stream_cur(), a.rowptr, a.val, n);
+  if (n > 0) d2d(a.col, agg_dev, sizeof(int) * (size_t)n);
+  return a;
+}
 Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val) {
   Csr a;
   a.n = n;
@@ -775,10 +794,11 @@ Csr csr_remap_columns(const Csr& a, const int* map_dev) {
 // (atomicCAS on the keys only), compacted, sorted (bitonic) and written; the values are then accumulated
 // owner-computes: lane t owns the sorted columns t, t+64, ... and scans ALL products of the row in the fixed
 // (k, l) order, so every sum has a fixed order whatever the hash did.  Capacity: SPG_MAXD distinct columns per row.
-constexpr int SPG_HS = 1024;     // hash slots per wave (load factor <= 0.25)
+constexpr int SPG_HS = 512;      // hash slots per wave (load factor <= 0.5 at the row capacity; typical rows hold 10-60 columns)
 constexpr int SPG_MAXD = 256;    // distinct columns per output row
 constexpr int SPG_KMAX = 256;    // entries of a row of A whose product offsets fit the wave's LDS prefix table
 constexpr int SPG_CHUNK = 256;   // products staged per round of the numeric phase
+__device__ int g_spgemm_no_small = 0;   // validation: 1 sends the <= 64-product rows through the hash table as well
 // Round 3: the products of an output row are FLATTENED over the wave.  Round 2 walked the row of A entry by entry and let
 // the lanes stride over the matching row of B -- with the 5-to-30-entry rows of P, A P and R that kept 5 to 30 of 64
 // lanes busy in the symbolic pass, and the numeric pass fetched every product's (column, value) from global memory inside
@@ -825,12 +845,13 @@ __device__ __forceinline__ void spg_insert(int* keys, int key, int* overflow) {
     if (probe == SPG_HS - 1) *overflow = 1;
   }
 }
-// hash set of the distinct columns of output row `row`; returns the number of products (-1: long row, serial walk taken)
-__device__ __forceinline__ int spg_collect(const int* __restrict__ arp, const int* __restrict__ acol,
-                                           const int* __restrict__ brp, const int* __restrict__ bcol, int row,
-                                           int lane, int* keys, int* ja, int* pre, int* overflow) {
+// hash set of the distinct columns of output row `row` (total = spg_prefix's result: -1 = long row, serial walk)
+__device__ __forceinline__ void spg_collect(const int* __restrict__ arp, const int* __restrict__ acol,
+                                            const int* __restrict__ brp, const int* __restrict__ bcol, int row,
+                                            int lane, int* keys, const int* ja, const int* pre, int total, int* overflow) {
   for (int s = lane; s < SPG_HS; s += 64) keys[s] = -1;
-  const int total = spg_prefix(arp, acol, brp, row, lane, ja, pre);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   if (total >= 0) {
     const int na = arp[row + 1] - arp[row];
     for (int p = lane; p < total; p += 64) {
@@ -845,7 +866,37 @@ __device__ __forceinline__ int spg_collect(const int* __restrict__ arp, const in
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  return total;
+}
+// Rows of at most 64 products (A P0 and A P of a stencil matrix: 7 and ~25) never touch the hash table: one product per
+// lane, the (column, product number) pairs are sorted ACROSS THE LANES (bitonic network on shuffles, no LDS, no barrier),
+// equal columns end up side by side in product order, and the head lane of each run folds its run from the left -- the
+// same sum order as the scans, so the results are bit-identical, and the row leaves sorted.  Clearing, compacting and
+// sorting a 512-slot table per row was most of what these rows cost (1 M rows of A P0: 2.1 ms, of which 7 products each).
+__device__ __forceinline__ void spg_sort64(unsigned long long& ck, double& v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long ock = __shfl_xor(ck, j, 64);
+      const double ov = __shfl_xor(v, j, 64);
+      const bool take_min = (((lane & j) == 0) == ((lane & k) == 0));
+      const bool swap = take_min ? (ock < ck) : (ock > ck);
+      if (swap) { ck = ock; v = ov; }
+    }
+}
+// one product per lane: composite sort key (column << 6 | product number) and value; lanes without a product sort last
+__device__ __forceinline__ void spg_small_products(const int* __restrict__ brp, const int* __restrict__ bcol,
+                                                   const double* __restrict__ aval, const double* __restrict__ bval,
+                                                   int a0, int na, int total, int lane, const int* ja, const int* pre,
+                                                   unsigned long long& ck, double& v) {
+  ck = ~0ull;
+  v = 0.0;
+  if (lane < total) {
+    const int k = spg_find(pre, na, lane);
+    const int l = brp[ja[k]] + (lane - pre[k]);
+    ck = ((unsigned long long)(unsigned)bcol[l] << 6) | (unsigned)lane;
+    if (aval) v = aval[a0 + k] * bval[l];
+  }
 }
 __global__ __launch_bounds__(256) void k_spgemm_count(int n, const int* __restrict__ arp, const int* __restrict__ acol,
                                                       const int* __restrict__ brp, const int* __restrict__ bcol,
@@ -856,7 +907,19 @@ __global__ __launch_bounds__(256) void k_spgemm_count(int n, const int* __restri
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
-  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], overflow);
+  const int total = spg_prefix(arp, acol, brp, row, lane, ja[w], pre[w]);
+  if (total >= 0 && total <= 64 && !g_spgemm_no_small) {
+    unsigned long long ck;
+    double v;
+    spg_small_products(brp, bcol, nullptr, nullptr, arp[row], arp[row + 1] - arp[row], total, lane, ja[w], pre[w], ck, v);
+    spg_sort64(ck, v, lane);
+    const unsigned long long prev = __shfl_up(ck, 1, 64);
+    const bool head = (ck != ~0ull) && (lane == 0 || (prev >> 6) != (ck >> 6));
+    const unsigned long long heads = __ballot(head);
+    if (lane == 0) cnt[row] = __builtin_popcountll(heads);
+    return;
+  }
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], total, overflow);
   int c = 0;
   for (int s = lane; s < SPG_HS; s += 64) c += (keys[w][s] != -1) ? 1 : 0;
 #pragma unroll
@@ -883,21 +946,22 @@ __device__ __forceinline__ void wave_bitonic_sort(int* key, double* val, int N, 
       __builtin_amdgcn_wave_barrier();
     }
 }
-__global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restrict__ arp, const int* __restrict__ acol,
+__global__ __launch_bounds__(256) void k_spgemm_fill_scan(int n, const int* __restrict__ arp, const int* __restrict__ acol,
                                                      const double* __restrict__ aval, const int* __restrict__ brp,
                                                      const int* __restrict__ bcol, const double* __restrict__ bval,
                                                      const int* __restrict__ crp, int* __restrict__ ccol,
                                                      double* __restrict__ cval, int* __restrict__ overflow) {
   __shared__ __attribute__((aligned(16))) int keys[4][SPG_HS];
+  __shared__ __attribute__((aligned(16))) int stage[4][SPG_CHUNK * 3];
   __shared__ int list[4][SPG_MAXD];
   __shared__ int ja[4][SPG_KMAX];
   __shared__ int pre[4][SPG_KMAX + 1];
   __shared__ int cntl[4];
-  static_assert(SPG_CHUNK * 12 <= SPG_HS * 4, "the staging tiles live in the hash table's LDS");
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
-  const int total = spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], overflow);
+  const int total = spg_prefix(arp, acol, brp, row, lane, ja[w], pre[w]);
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], total, overflow);
   const int base = crp[row], cnt = crp[row + 1] - base;
   if (cnt > SPG_MAXD) return;   // flagged by the count pass
   if (lane == 0) cntl[w] = 0;
@@ -924,8 +988,8 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
     // the hash table has done its job (its keys are in `list`, sorted): its LDS now holds the staging tiles
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int* skey = keys[w];
-    double* sval = reinterpret_cast<double*>(keys[w] + SPG_CHUNK);
+    int* skey = stage[w] + 2 * SPG_CHUNK;
+    double* sval = reinterpret_cast<double*>(stage[w]);
     const int a0 = arp[row], na = arp[row + 1] - a0;
     for (int p0 = 0; p0 < total; p0 += SPG_CHUNK) {
       const int nc = (total - p0 < SPG_CHUNK) ? total - p0 : SPG_CHUNK;
@@ -983,6 +1047,132 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
       ccol[base + t] = mycol[u];
       cval[base + t] = acc[u];
     }
+  }
+}
+// Numeric pass, round-3 form (default): the hash table of the symbolic collect keeps its keys and gets one FP64 accumulator
+// per slot.  Products are taken 256 at a time (four per lane, all their loads in flight together), each finds its slot by
+// the probe sequence that inserted its column, and the additions run SEGMENT BY SEGMENT: the products of one entry k of
+// the A row hit pairwise different columns (a CSR row of B has none twice), so their read-modify-writes are independent,
+// and the segments follow each other in k order -- every output entry is summed in the (k, l) order of the owner-computes
+// scan above, bit for bit, but a product costs a handful of LDS operations instead of a compare in every lane
+// (R (A P) at 126^3: 1 250 products for ~30 columns per row).  The (column, sum) pairs are then compacted and sorted.
+__device__ __forceinline__ int spg_lookup(const int* keys, int key) {
+  unsigned h = ((unsigned)key * 2654435761u) & (SPG_HS - 1);
+  while (keys[h] != key) h = (h + 1) & (SPG_HS - 1);
+  return (int)h;
+}
+__global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restrict__ arp, const int* __restrict__ acol,
+                                                     const double* __restrict__ aval, const int* __restrict__ brp,
+                                                     const int* __restrict__ bcol, const double* __restrict__ bval,
+                                                     const int* __restrict__ crp, int* __restrict__ ccol,
+                                                     double* __restrict__ cval, int* __restrict__ overflow) {
+  __shared__ int keys[4][SPG_HS];
+  __shared__ double hval[4][SPG_HS];
+  __shared__ int list[4][SPG_MAXD];
+  __shared__ double lval[4][SPG_MAXD];
+  __shared__ int ja[4][SPG_KMAX];
+  __shared__ int pre[4][SPG_KMAX + 1];
+  __shared__ int cntl[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= n) return;
+  const int total = spg_prefix(arp, acol, brp, row, lane, ja[w], pre[w]);
+  const int base = crp[row], cnt = crp[row + 1] - base;
+  if (cnt > SPG_MAXD) return;   // flagged by the count pass
+  if (total >= 0 && total <= 64 && !g_spgemm_no_small) {
+    unsigned long long ck;
+    double v;
+    spg_small_products(brp, bcol, aval, bval, arp[row], arp[row + 1] - arp[row], total, lane, ja[w], pre[w], ck, v);
+    spg_sort64(ck, v, lane);
+    const unsigned long long prev = __shfl_up(ck, 1, 64);
+    const bool head = (ck != ~0ull) && (lane == 0 || (prev >> 6) != (ck >> 6));
+    double acc = 0.0 + v;                          // the scans start every sum at +0.0
+    for (int d = 1; d < 64; ++d) {                 // left fold of each run into its head lane, in product order
+      const unsigned long long nk = __shfl_down(ck, d, 64);
+      const double nv = __shfl_down(v, d, 64);
+      const bool more = head && lane + d < 64 && (nk >> 6) == (ck >> 6);
+      if (more) acc += nv;
+      if (!__ballot(more)) break;
+    }
+    const unsigned long long heads = __ballot(head);
+    if (head) {
+      const int pos = __builtin_popcountll(heads & ((1ull << lane) - 1ull));
+      ccol[base + pos] = (int)(ck >> 6);
+      cval[base + pos] = acc;
+    }
+    return;
+  }
+  spg_collect(arp, acol, brp, bcol, row, lane, keys[w], ja[w], pre[w], total, overflow);
+  const int* kw = keys[w];
+  double* hv = hval[w];
+  for (int s = lane; s < SPG_HS; s += 64) hv[s] = 0.0;
+  if (lane == 0) cntl[w] = 0;
+  for (int t = lane; t < SPG_MAXD; t += 64) list[w][t] = 0x7fffffff;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int a0 = arp[row], na = arp[row + 1] - a0;
+  if (total >= 0) {
+    constexpr int NB = 4;                         // products per lane and round
+    for (int p0 = 0; p0 < total; p0 += 64 * NB) {
+      int kk[NB], slot[NB];
+      double vv[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int p = p0 + 64 * t + lane;
+        kk[t] = (p < total) ? spg_find(pre[w], na, p) : 0x7fffffff;
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        slot[t] = 0;
+        vv[t] = 0.0;
+        if (kk[t] != 0x7fffffff) {
+          const int l = brp[ja[w][kk[t]]] + (p0 + 64 * t + lane - pre[w][kk[t]]);
+          slot[t] = bcol[l];                      // the column for now
+          vv[t] = aval[a0 + kk[t]] * bval[l];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        if (kk[t] != 0x7fffffff) slot[t] = spg_lookup(kw, slot[t]);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        if (p0 + 64 * t >= total) break;          // wave-uniform
+        int kc = __builtin_amdgcn_readfirstlane(kk[t]);   // lane 0 of a started batch holds a product
+        while (true) {
+          if (kk[t] == kc) hv[slot[t]] += vv[t];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          const unsigned long long later = __ballot(kk[t] != 0x7fffffff && kk[t] > kc);
+          if (!later) break;
+          kc = __shfl(kk[t], __builtin_ctzll(later), 64);
+        }
+      }
+    }
+  } else {
+    for (int k = a0; k < a0 + na; ++k) {          // long row of A: entry by entry, lanes over the row of B
+      const int j = acol[k];
+      const double av = aval[k];
+      for (int l = brp[j] + lane; l < brp[j + 1]; l += 64) hv[spg_lookup(kw, bcol[l])] += av * bval[l];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int s = lane; s < SPG_HS; s += 64) {
+    const int key = kw[s];
+    if (key != -1) {
+      const int t = atomicAdd(&cntl[w], 1);
+      list[w][t] = key;
+      lval[w][t] = hv[s];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int N = 64;
+  while (N < cnt) N <<= 1;
+  wave_bitonic_sort(list[w], lval[w], N, lane);
+  for (int t = lane; t < cnt; t += 64) {
+    ccol[base + t] = list[w][t];
+    cval[base + t] = lval[w][t];
   }
 }
 // rowptr[0..n] from the counts in rowptr[1..n]: inclusive scan on the device (round 2 took the counts to the host and back:
@@ -1114,8 +1304,12 @@ Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
   c.nnz = total;
   c.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)total));
   c.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)total));
-  hipLaunchKernelGGL(k_spgemm_fill, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
-                     b.col, b.val, c.rowptr, c.col, c.val, dflag);
+  if (g_spgemm_fill_scan)
+    hipLaunchKernelGGL(k_spgemm_fill_scan, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
+                       b.col, b.val, c.rowptr, c.col, c.val, dflag);
+  else
+    hipLaunchKernelGGL(k_spgemm_fill, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
+                       b.col, b.val, c.rowptr, c.col, c.val, dflag);
   d2h(&hflag, dflag, sizeof(int));
   dfree(dflag);
   if (hflag) {
@@ -3074,6 +3268,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
   }
 }
 
+// The two shapes LOBPCG launches every iteration / every 8th iteration, with 16-byte streaming loads (round 3):
+//   TWO = true :  [A1 | A2]^T T, two left blocks of 16 TI columns each (A W and B W inside the 96-wide A S / B S rows)
+//   TWO = false:  A1^T T, one left block of 32 TI columns
+// against a right operand of 32 TJ columns.  A 16-row slab goes HBM -> registers as 16-byte units (the right operand's
+// slab is one contiguous block when ldt == q: thread t copies units t, t + 256, ...), non-temporal (every byte is read
+// once), -> LDS as ds_write_b128, and the MFMA phase is k_gram_mfma's: per output tile the same sequence of 4-row steps in
+// ascending row order, so the partial matrices are bit-identical to k_gram_mfma<TI, TJ, *>'s.  W-row Gram of 2.29 M rows:
+// 0.71 -> 0.55 ms (4.1 -> 5.3 TB/s, 39.6 -> 50.9 TFLOP/s; a read-only stream of the same bytes takes 0.43 ms);
+// scripts/dev/gram_bench.hip holds the variants that were measured (32-row slabs, two LDS slabs: no better).
+template <int TI, int TJ, bool TWO>
+__global__ __launch_bounds__(256) void k_gram_flat(const int* __restrict__ cstart, const int* __restrict__ clen,
+                                                   const int* __restrict__ gfirst, const double* __restrict__ A1,
+                                                   const double* __restrict__ A2, int lda, const double* __restrict__ T,
+                                                   int ldt_, double* __restrict__ Gpart) {
+  typedef spmm_d2 d2;
+  constexpr int p = 32 * TI, q = 32 * TJ, ldS = p + 16, ldT = q + 16, SR = 16;
+  constexpr int UT = q / 2;                        // 16-byte units per row of the right operand
+  constexpr int UL = TWO ? p / 4 : p / 2;          // units per row of one left block
+  constexpr int NUT = (SR * UT + 255) / 256, NUL = (SR * UL + 255) / 256;
+  __shared__ __attribute__((aligned(16))) double sS[SR * ldS];
+  __shared__ __attribute__((aligned(16))) double sT[SR * ldT];
+  const int g = blockIdx.x;
+  const int c0 = gfirst[g];
+  const int row0 = cstart[c0], nrows = clen[c0];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int wi = w >> 1, wj = w & 1;
+  int aoff[TI], boff[TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a) aoff[a] = 16 * (wi * TI + a) + (l & 15);
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) boff[b] = 16 * (wj * TJ + b) + (l & 15);
+  d4 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  d2 rt[NUT], r1[NUL], r2[TWO ? NUL : 1];
+  auto load_slab = [&](int r) {
+    const int nr = (nrows - r < SR) ? nrows - r : SR;
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+      const int u = tid + 256 * j, rr = u / UT, cu = u - rr * UT;
+      const bool ok = (SR * UT % 256 == 0 || u < SR * UT) && rr < nr;
+      rt[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(T + (int64_t)(row0 + r + rr) * ldt_ + 2 * cu))
+                 : d2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int j = 0; j < NUL; ++j) {
+      const int u = tid + 256 * j, rr = u / UL, cu = u - rr * UL;
+      const bool ok = (SR * UL % 256 == 0 || u < SR * UL) && rr < nr;
+      const int64_t off = (int64_t)(row0 + r + (ok ? rr : 0)) * lda + 2 * cu;
+      r1[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(A1 + off)) : d2{0.0, 0.0};
+      if (TWO) r2[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(A2 + off)) : d2{0.0, 0.0};
+    }
+  };
+  load_slab(0);
+  for (int r = 0; r < nrows; r += SR) {
+    __syncthreads();  // every wave is done reading the previous slab
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+      const int u = tid + 256 * j, rr = u / UT, cu = u - rr * UT;
+      if (SR * UT % 256 == 0 || u < SR * UT) *reinterpret_cast<d2*>(sT + rr * ldT + 2 * cu) = rt[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NUL; ++j) {
+      const int u = tid + 256 * j, rr = u / UL, cu = u - rr * UL;
+      if (SR * UL % 256 == 0 || u < SR * UL) {
+        *reinterpret_cast<d2*>(sS + rr * ldS + 2 * cu) = r1[j];
+        if (TWO) *reinterpret_cast<d2*>(sS + rr * ldS + p / 2 + 2 * cu) = r2[j];
+      }
+    }
+    __syncthreads();
+    if (r + SR < nrows) load_slab(r + SR);  // in flight during the MFMA phase
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int kr = 4 * step + (l >> 4);
+      double av[TI], bv[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; ++a) av[a] = sS[kr * ldS + aoff[a]];
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) bv[b] = sT[kr * ldT + boff[b]];
+#pragma unroll
+      for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  double* G = Gpart + (int64_t)g * p * q;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 16 * (wi * TI + a) + (l >> 4) + 4 * v, colj = 16 * (wj * TJ + b) + (l & 15);
+        G[(int64_t)row * q + colj] = acc[a][b][v];
+      }
+}
+
 // plain-FMA twin (any p, q): each thread owns output entries e = tid, tid+256, ...
 __global__ __launch_bounds__(256) void k_gram_fma(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                   const int* __restrict__ gfirst, const int* __restrict__ gcount,
@@ -3201,7 +3494,16 @@ static void gram_impl(const Chunks& c, const double* S, int lds_, int p, const d
     pl.part_doubles = need;
   }
   const bool mfma_ok = !g_no_mfma && (p % 16 == 0) && (q % 16 == 0) && p <= 192 && q <= 192;
-  if (mfma_ok) {
+  // LOBPCG's two shapes on 16-byte streaming loads (k_gram_flat; bit-identical partial matrices)
+  static_assert(GRAM_CH == 1, "k_gram_flat takes one chunk per workgroup");
+  const bool flat_base = mfma_ok && g_gram_flat && q == 96 && (ldt_ % 2 == 0) && (lds_ % 2 == 0) && aligned16(S) && aligned16(T);
+  if (flat_base && S2 && p == 64 && psplit == 32 && lds2_ == lds_ && aligned16(S2)) {
+    hipLaunchKernelGGL((k_gram_flat<2, 3, true>), dim3(pl.ngroup), dim3(256), 0, g_stream, c.start, c.len, pl.gfirst, S, S2,
+                       lds_, T, ldt_, pl.part);
+  } else if (flat_base && !S2 && p == 96) {
+    hipLaunchKernelGGL((k_gram_flat<3, 3, false>), dim3(pl.ngroup), dim3(256), 0, g_stream, c.start, c.len, pl.gfirst, S,
+                       nullptr, lds_, T, ldt_, pl.part);
+  } else if (mfma_ok) {
     const int ldS = (p % 32 == 0) ? p + 16 : p, ldT = (q % 32 == 0) ? q + 16 : q;
     const size_t sm = sizeof(double) * 16 * (size_t)(ldS + ldT);
     const int P16 = p / 16, Q16 = q / 16;
@@ -3400,7 +3702,13 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
                                                         const double* __restrict__ lam, const double* __restrict__ mask,
                                                         double* __restrict__ T, double* __restrict__ AT,
                                                         double* __restrict__ BT, double* __restrict__ R) {
-  constexpr int m = 32, p = 96, q = 64, ldS = p + 1, SR = 32;
+  // Round 3: a 32-row slab of a 96-wide operand is ONE contiguous 24 KiB block, copied as 16-byte units (thread t takes
+  // units t, t + 256, ...: 6 per thread) with non-temporal loads, and the outputs leave through non-temporal stores --
+  // every byte of this kernel is touched once.  Same MFMA sequence per output tile as before (bit-identical results);
+  // 2.29 M rows: 1.69 -> 1.61 ms = 5.8 TB/s, where a plain copy of the same access pattern reaches 5.3 TB/s
+  // (scripts/dev/update_bench.hip; neither two slabs in flight nor shorter workgroups change it).
+  typedef spmm_d2 d2;
+  constexpr int m = 32, p = 96, q = 64, ldS = p + 1, SR = 32, NU = SR * (p / 2) / 256;
   __shared__ double sS[SR * ldS];
   const int c = blockIdx.x;
   const int row0 = cstart[c], nrows = clen[c], sd = csub[c];
@@ -3416,17 +3724,21 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
   const double kp = keep[sd * m + col], lm = lam[sd * m + col], mk = mask ? mask[sd * m + col] : 1.0;
   const double* src[3] = {S, AS, BS};
   double* dst[3] = {T, AT, BT};
-  double rg[SR / 4][2];
-  auto load_slab = [&](int t) {        // t = 3 * slab + operand
-    const double* base = src[t % 3];
-    const int r = (t / 3) * SR;
+  int loff[NU];                                    // LDS offset of this thread's j-th unit (odd row stride: two b64 writes)
 #pragma unroll
-    for (int u = 0; u < SR / 4; ++u) {
-      const int rr = r + (SR / 4) * w + u;
-      const bool ok = rr < nrows;
-      const double* srow = base + (int64_t)(row0 + (ok ? rr : 0)) * p;
-      rg[u][0] = ok ? srow[l] : 0.0;
-      rg[u][1] = (ok && l < 32) ? srow[64 + l] : 0.0;
+  for (int j = 0; j < NU; ++j) {
+    const int u = tid + 256 * j;
+    loff[j] = (u / (p / 2)) * ldS + 2 * (u % (p / 2));
+  }
+  d2 rg[NU];
+  auto load_slab = [&](int t) {        // t = 3 * slab + operand
+    const int r = (t / 3) * SR;
+    const int nr = (nrows - r < SR) ? nrows - r : SR;
+    const d2* base = reinterpret_cast<const d2*>(src[t % 3] + (int64_t)(row0 + r) * p);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = tid + 256 * j;
+      rg[j] = (u < nr * (p / 2)) ? __builtin_nontemporal_load(base + u) : d2{0.0, 0.0};
     }
   };
   const int nt = 3 * ((nrows + SR - 1) / SR);
@@ -3437,9 +3749,9 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
     const int nr = (nrows - r < SR) ? nrows - r : SR;
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < SR / 4; ++u) {
-      sS[((SR / 4) * w + u) * ldS + l] = rg[u][0];
-      if (l < 32) sS[((SR / 4) * w + u) * ldS + 64 + l] = rg[u][1];
+    for (int j = 0; j < NU; ++j) {
+      sS[loff[j]] = rg[j].x;
+      sS[loff[j] + 1] = rg[j].y;
     }
     __syncthreads();
     if (t + 1 < nt) load_slab(t + 1);
@@ -3452,21 +3764,21 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int rr = 16 * rt + (l >> 4) + 4 * v;
-        if (rr < nr) out[(int64_t)(row0 + r + rr) * p + m + col] = kp * acc[v];
+        if (rr < nr) __builtin_nontemporal_store(kp * acc[v], out + (int64_t)(row0 + r + rr) * p + m + col);
       }
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * kk], bx[kk], acc, 0, 0, 0);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int rr = 16 * rt + (l >> 4) + 4 * v;
-        if (rr < nr) out[(int64_t)(row0 + r + rr) * p + col] = acc[v];
+        if (rr < nr) __builtin_nontemporal_store(acc[v], out + (int64_t)(row0 + r + rr) * p + col);
       }
       if (op == 1) ax = acc;
       if (op == 2) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int rr = 16 * rt + (l >> 4) + 4 * v;
-          if (rr < nr) R[(int64_t)(row0 + r + rr) * m + col] = mk * (ax[v] - lm * acc[v]);
+          if (rr < nr) __builtin_nontemporal_store(mk * (ax[v] - lm * acc[v]), R + (int64_t)(row0 + r + rr) * m + col);
         }
       }
     }
@@ -3476,6 +3788,7 @@ void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const d
                      const double* keep, const double* lam, const double* mask, double* T, double* AT, double* BT,
                      double* R) {
   if (c.nchunk == 0) return;
+  if (!aligned16(S) || !aligned16(AS) || !aligned16(BS)) throw std::runtime_error("lobpcg_update32: operands must be 16-byte aligned");
   // counted with the block updates it replaces (three of them): same class, bytes and flops of the fused form
   ProfScope prof(PROF_BLOCKMUL, true, 8.0 * (double)c.n * (3 * 96 + 3 * 64 + 32), 2.0 * (double)c.n * (64 * 32 + 32 * 32) * 3);
   hipLaunchKernelGGL(k_lobpcg_update32, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, AS, BS, C, keep,
@@ -3935,6 +4248,18 @@ __global__ void k_mfma_selftest(double* out) {
   }
 }
 void set_mfma(bool enable) { lazy_init(); g_no_mfma = !enable; }
+bool set_variant(const char* name, int value) {
+  const std::string k(name ? name : "");
+  if (k == "spgemm_fill_scan") { g_spgemm_fill_scan = value != 0; return true; }
+  if (k == "gram_flat") { g_gram_flat = value != 0; return true; }
+  if (k == "spgemm_small_rows") {
+    lazy_init();
+    const int off = value ? 0 : 1;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_spgemm_no_small), &off, sizeof(int)));
+    return true;
+  }
+  return false;
+}
 int selftest_mfma_f64() {
   double* d = (double*)alloc(sizeof(double) * 256);
   hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, g_stream, d);

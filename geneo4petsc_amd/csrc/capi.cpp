@@ -509,6 +509,7 @@ PetscErrorCode GeneoSetMFMA(int enable) {
   bk::set_mfma(enable != 0);
   return 0;
 }
+PetscErrorCode GeneoSetKernelVariant(const char* name, int value) { return bk::set_variant(name, value) ? 0 : 1; }
 
 // ---- stand-alone kernels --------------------------------------------------------------------
 PetscErrorCode GeneoSpmvCreate(const GeneoCsr* a, GeneoSpmv* h) {

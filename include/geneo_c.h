@@ -284,6 +284,11 @@ PetscErrorCode GeneoTestAxpby(double* y_dev, const double* x_dev, double a, doub
 PetscErrorCode GeneoSetSpmvKind(int kind);       /* 0: LDS row-block SpMV kernel, 1: 64-row sliced kernel (default) */
 const char* GeneoSpmvKernelName(void);
 PetscErrorCode GeneoSetMFMA(int enable);         /* 0: run the plain-FMA twins of the MFMA kernels (validation) */
+/* validation: choose between two device forms of the same arithmetic -- "spgemm_fill_scan" (1: owner-computes numeric pass
+ * of the sparse products instead of the hash accumulators), "spgemm_small_rows" (0: rows of at most 64 products go through
+ * the hash table as well), "gram_flat" (0: k_gram_mfma instead of k_gram_flat); both forms of each give bit-identical
+ * results (tests/test_gpu_kernels.py).  Returns 1 for an unknown name. */
+PetscErrorCode GeneoSetKernelVariant(const char* name, int value);
 
 /* ---- stand-alone kernels (parity tests and the roofline leg of bench.py) --------------------- */
 typedef struct _p_GeneoSpmv* GeneoSpmv;

@@ -103,6 +103,12 @@ void smooth_prolongator(Csr& ap0, const int* agg, const double* dinv, double w) 
 }
 void csr_finish(Csr&) {}
 Csr csr_upload_raw(int n, const int* rp, const int* col, const double* val) { return csr_upload(n, rp, col, val); }
+Csr csr_tentative_prolongator(int n, const int* agg) {
+  std::vector<int> rp(n + 1);
+  for (int i = 0; i <= n; ++i) rp[i] = i;
+  std::vector<double> ones(n, 1.0);
+  return csr_upload(n, rp.data(), agg, ones.data());
+}
 void csr_download(const Csr& a, int* rowptr, int* col, double* val) {
   memcpy(rowptr, a.rowptr, sizeof(int) * (a.n + 1));
   memcpy(col, a.col, sizeof(int) * a.nnz);
@@ -553,6 +559,7 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
   }
 }
 void set_mfma(bool) {}
+bool set_variant(const char*, int) { return false; }
 void set_spmv_kind(int) {}
 const char* spmv_kernel_name() { return "hostsim"; }
 int selftest_mfma_f64() { return 0; }

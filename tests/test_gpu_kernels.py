@@ -301,6 +301,72 @@ def test_device_sparse_products(lib, n, m, k, density):
         assert np.all(np.diff(r) > 0)
 
 
+def test_device_sparse_product_forms_agree_bitwise(lib):
+    """Numeric pass of the sparse products: hash accumulators (default) == owner-computes scan (round 2), to the bit, on a
+    multigrid-like chain A P0, A P, R (A P) -- the sums are taken in the same (k, l) order in both."""
+    from geneo4petsc_amd.pc import sparse_product
+    n = 20
+    e = np.ones(n)
+    t = sp.diags([-e[:-1], 2.0001 * e, -e[:-1]], [-1, 0, 1])
+    i = sp.identity(n)
+    a = (sp.kron(sp.kron(t, i), i) + sp.kron(sp.kron(i, t), i) + sp.kron(sp.kron(i, i), t)).tocsr()
+    a.data *= 1.0 + 0.37 * np.sin(np.arange(a.nnz))           # no two products alike
+    agg = (np.arange(n ** 3) // 3) // 1
+    agg = np.minimum(agg // 3, n ** 3 // 9 - 1)
+    p0 = sp.csr_matrix((np.ones(n ** 3), (np.arange(n ** 3), agg)), shape=(n ** 3, n ** 3 // 9))
+    P = (p0 - 0.6 * sp.diags(1.0 / a.diagonal()) @ (a @ p0)).tocsr()
+    P.sort_indices()
+    R = P.T.tocsr()
+    R.sort_indices()
+    ap = (a @ P).tocsr()
+    ap.sort_indices()
+    dense_left = sp.csr_matrix(np.random.default_rng(5).random((3, 300)))      # rows longer than the prefix table holds
+    dense_right = sp.random(300, 200, density=0.3, random_state=np.random.default_rng(6), format="csr")
+    dense_right.sort_indices()
+    for x, y in ((a, p0), (a, P), (R, ap), (dense_left, dense_right)):
+        y = y.tocsr()
+        y.sort_indices()
+        assert lib.GeneoSetKernelVariant(b"spgemm_fill_scan", 1) == 0
+        try:
+            old = sparse_product(x, y, lib)
+        finally:
+            lib.GeneoSetKernelVariant(b"spgemm_fill_scan", 0)
+        new = sparse_product(x, y, lib)
+        assert lib.GeneoSetKernelVariant(b"spgemm_small_rows", 0) == 0      # short rows through the hash table as well
+        try:
+            mid = sparse_product(x, y, lib)
+        finally:
+            lib.GeneoSetKernelVariant(b"spgemm_small_rows", 1)
+        assert old is not None and new is not None and mid is not None
+        for other in (new, mid):
+            assert np.array_equal(old.indptr, other.indptr) and np.array_equal(old.indices, other.indices)
+            assert np.array_equal(old.data.view(np.uint64), other.data.view(np.uint64))
+        ref = (x @ y).tocsr()
+        assert abs(new - ref).max() <= 1e-13 * abs(ref).max()
+    assert lib.GeneoSetKernelVariant(b"no such switch", 1) == 1
+
+
+@pytest.mark.parametrize("kind,p", [(2, 64), (0, 96)])
+def test_gram_streaming_form_agrees_bitwise(lib, kind, p):
+    """LOBPCG's two Gram shapes (W rows: p = 32 + 32; full: p = 96; q = 96): k_gram_flat == k_gram_mfma to the bit, ragged
+    chunks included (same sequence of 4-row MFMA steps per output tile)."""
+    from geneo4petsc_amd.pc import block_kernel
+    rng = np.random.default_rng(43)
+    suboff = np.array([0, 700, 1500, 1501, 4000, 4000 + 1024 * 3 + 5], dtype=np.int32)
+    nrow = int(suboff[-1])
+    S, T = rng.random((nrow, p)) - 0.5, rng.random((nrow, 96)) - 0.5
+    assert lib.GeneoSetKernelVariant(b"gram_flat", 0) == 0
+    try:
+        g_old, _ = block_kernel(kind, suboff, S, T, lib)
+    finally:
+        lib.GeneoSetKernelVariant(b"gram_flat", 1)
+    g_new, _ = block_kernel(kind, suboff, S, T, lib)
+    assert np.array_equal(g_old.view(np.uint64), g_new.view(np.uint64))
+    for s in range(len(suboff) - 1):
+        r = slice(suboff[s], suboff[s + 1])
+        np.testing.assert_allclose(g_new[s], S[r].T @ T[r], rtol=1e-12, atol=1e-12)
+
+
 def test_device_sparse_product_reports_overflow(lib):
     """More than 256 distinct columns in one output row: the kernels say so and the caller uses the host product."""
     from geneo4petsc_amd.pc import sparse_product
