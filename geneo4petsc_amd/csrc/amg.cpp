@@ -153,15 +153,45 @@ static HostCsr spgemm(const HostCsr& a, const HostCsr& b, int ncols_b) {
 
 // Vanek-style aggregation inside one diagonal block [r0, r1): returns #aggregates, agg[i] local ids.
 // theta > 0: only STRONG connections |a_ij| >= theta sqrt(a_ii a_jj) tie nodes together (Vanek, Mandel, Brezina 1996).
-static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& agg, double theta = 0.0) {
+//
+// Round 3: the greedy seeding pass (phase 1) is inherently serial, everything around it is not.  The strong neighbour
+// lists are gathered first, in row ranges on `nthreads` host threads (one pass over the block's entries: the diagonal
+// and the strength test read 12 bytes per entry, the serial pass then walks 4 bytes per STRONG entry -- a coarse Galerkin
+// operator of 31 entries per row keeps about a quarter of them), and the leftovers' choice of an aggregate (phase 2, which
+// reads the aggregates of phase 1 and writes only its own row) runs in row ranges as well.  Same predicate, same visiting
+// order, same tie-breaking: the aggregates are the ones the serial loops produced (tests: iteration counts unchanged).
+// One 869 k-row block of 26.5 M entries (first coarse level of one rank of 368^3): 0.07 -> 0.02 s.
+static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& agg, double theta = 0.0, int nthreads = 1) {
   int na = 0;
-  for (int i = r0; i < r1; ++i) agg[i] = -1;
+  const int nb = r1 - r0;
+  if (nb <= 0) return 0;
+  {   // test switches: GENEO_AGG_THREADS forces the thread count, GENEO_AGG_MIN_NNZ the size below which one thread does it all
+    const char* ft = getenv("GENEO_AGG_THREADS");
+    const char* fm = getenv("GENEO_AGG_MIN_NNZ");
+    if (ft) nthreads = atoi(ft);
+    if ((int64_t)a.rowptr[r1] - a.rowptr[r0] < (fm ? atoll(fm) : 4000000LL)) nthreads = 1;
+    nthreads = std::max(1, std::min(nthreads, ft ? nb : nb / 4096 + 1));
+  }
+  auto ranges = [&](const std::function<void(int, int, int)>& f) {       // f(thread, row begin, row end)
+    if (nthreads == 1) { f(0, r0, r1); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t)
+      th.emplace_back([&, t]() { f(t, r0 + (int)((int64_t)nb * t / nthreads), r0 + (int)((int64_t)nb * (t + 1) / nthreads)); });
+    f(0, r0, r0 + (int)((int64_t)nb / nthreads));
+    for (auto& x : th) x.join();
+  };
   std::vector<double> dg;
   if (theta > 0.0) {
-    dg.assign(r1 - r0, 0.0);
-    for (int i = r0; i < r1; ++i)
-      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
-        if (a.col[k] == i) dg[i - r0] = std::fabs(a.val[k]);
+    dg.assign(nb, 0.0);
+    ranges([&](int, int b, int e) {
+      for (int i = b; i < e; ++i) {
+        agg[i] = -1;
+        for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
+          if (a.col[k] == i) dg[i - r0] = std::fabs(a.val[k]);
+      }
+    });
+  } else {
+    ranges([&](int, int b, int e) { for (int i = b; i < e; ++i) agg[i] = -1; });
   }
   const double t2 = theta * theta;
   auto strong = [&](int i, int k) {
@@ -172,35 +202,63 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
     if (j < r0 || j >= r1) return false;
     return v * v >= t2 * dg[i - r0] * dg[j - r0];
   };
-  for (int i = r0; i < r1; ++i) {  // phase 1: a free node whose whole (strong) neighbourhood is free seeds an aggregate
-    if (agg[i] >= 0) continue;
-    bool ok = true;
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
-      const int j = a.col[k];
-      if (j != i && strong(i, k) && agg[j] >= 0) { ok = false; break; }
+  // strong neighbour lists (diagonal included when it passes the test, as the loops below always treated it), per range
+  std::vector<std::vector<int>> scol(nthreads);
+  std::vector<int> scnt(nb, 0);
+  ranges([&](int t, int b, int e) {
+    std::vector<int>& out = scol[t];
+    out.reserve((size_t)(a.rowptr[e] - a.rowptr[b]) / (theta > 0.0 ? 3 : 1) + 16);
+    for (int i = b; i < e; ++i) {
+      int c = 0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
+        if (strong(i, k)) { out.push_back(a.col[k]); ++c; }
+      scnt[i - r0] = c;
     }
-    if (!ok) continue;
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k)
-      if (strong(i, k)) agg[a.col[k]] = na;
-    agg[i] = na++;
+  });
+  for (int t = 0; t < nthreads; ++t) {   // phase 1: a free node whose whole (strong) neighbourhood is free seeds an aggregate
+    const int b = (t == 0) ? r0 : r0 + (int)((int64_t)nb * t / nthreads);
+    const int e = (nthreads == 1) ? r1 : r0 + (int)((int64_t)nb * (t + 1) / nthreads);
+    const int* sp = scol[t].data();
+    for (int i = b; i < e; ++i) {
+      const int c = scnt[i - r0];
+      if (agg[i] < 0) {
+        bool ok = true;
+        for (int k = 0; k < c; ++k) {
+          const int j = sp[k];
+          if (j != i && agg[j] >= 0) { ok = false; break; }
+        }
+        if (ok) {
+          for (int k = 0; k < c; ++k) agg[sp[k]] = na;
+          agg[i] = na++;
+        }
+      }
+      sp += c;
+    }
   }
-  std::vector<int> join(r1 - r0, -1);
-  for (int i = r0; i < r1; ++i) {  // phase 2: leftovers join the most strongly connected aggregate
-    if (agg[i] >= 0) continue;
-    double best = 0.0;
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
-      const int j = a.col[k];
-      if (j != i && agg[j] >= 0 && std::fabs(a.val[k]) > best) {
-        best = std::fabs(a.val[k]);
-        join[i - r0] = agg[j];
+  std::vector<int> join(nb, -1);
+  ranges([&](int, int b, int e) {        // phase 2: leftovers join the most strongly connected aggregate (of phase 1)
+    for (int i = b; i < e; ++i) {
+      if (agg[i] >= 0) continue;
+      double best = 0.0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+        const int j = a.col[k];
+        if (j != i && agg[j] >= 0 && std::fabs(a.val[k]) > best) {
+          best = std::fabs(a.val[k]);
+          join[i - r0] = agg[j];
+        }
       }
     }
-  }
+  });
   for (int i = r0; i < r1; ++i)
     if (agg[i] < 0 && join[i - r0] >= 0) agg[i] = join[i - r0];
   for (int i = r0; i < r1; ++i)  // phase 3: isolated nodes
     if (agg[i] < 0) agg[i] = na++;
   return na;
+}
+// host threads one block's aggregation may use when `nblocks` of them run side by side
+static int aggregate_threads(int nblocks) {
+  const int hw = std::max(1, (int)std::thread::hardware_concurrency());
+  return std::max(1, std::min(16, hw / std::max(1, nblocks)));
 }
 
 // Strength threshold of level l.  Level 0 keeps every entry (the operators handed in are mesh matrices: an M-matrix
@@ -321,7 +379,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
       std::vector<int> nagg(nsub, 0);
       std::vector<std::thread> th;
       for (int s = 0; s < nsub; ++s)
-        th.emplace_back([&, s]() { nagg[s] = aggregate_block(LA, L.suboff[s], L.suboff[s + 1], agg, amg_strength(prm, (int)levels.size() - 1)); });
+        th.emplace_back([&, s]() { nagg[s] = aggregate_block(LA, L.suboff[s], L.suboff[s + 1], agg, amg_strength(prm, (int)levels.size() - 1), aggregate_threads(nsub)); });
       for (auto& x : th) x.join();
       for (int s = 0; s < nsub; ++s) csub[s + 1] = csub[s] + nagg[s];
       for (int s = 0; s < nsub; ++s)
@@ -549,7 +607,7 @@ AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& 
     std::vector<int> nagg(nsub, 0);
     std::vector<std::thread> th;
     for (int s = 0; s < nsub; ++s)
-      th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], h.agg, amg_strength(prm, l)); });
+      th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], h.agg, amg_strength(prm, l), aggregate_threads(nsub)); });
     for (auto& x : th) x.join();
     for (int s = 0; s < nsub; ++s) h.csub[s + 1] = h.csub[s] + nagg[s];
     for (int s = 0; s < nsub; ++s)

@@ -900,13 +900,15 @@ __device__ __forceinline__ void spg_small_products(const int* __restrict__ brp, 
 }
 __global__ __launch_bounds__(256) void k_spgemm_count(int n, const int* __restrict__ arp, const int* __restrict__ acol,
                                                       const int* __restrict__ brp, const int* __restrict__ bcol,
-                                                      int* __restrict__ cnt, int* __restrict__ overflow) {
+                                                      int* __restrict__ cnt, int* __restrict__ overflow,
+                                                      const unsigned char* __restrict__ defer) {
   __shared__ int keys[4][SPG_HS];
   __shared__ int ja[4][SPG_KMAX];
   __shared__ int pre[4][SPG_KMAX + 1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
+  if (defer && !defer[row]) return;       // done by k_spgemm_small
   const int total = spg_prefix(arp, acol, brp, row, lane, ja[w], pre[w]);
   if (total >= 0 && total <= 64 && !g_spgemm_no_small) {
     unsigned long long ck;
@@ -1065,7 +1067,8 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
                                                      const double* __restrict__ aval, const int* __restrict__ brp,
                                                      const int* __restrict__ bcol, const double* __restrict__ bval,
                                                      const int* __restrict__ crp, int* __restrict__ ccol,
-                                                     double* __restrict__ cval, int* __restrict__ overflow) {
+                                                     double* __restrict__ cval, int* __restrict__ overflow,
+                                                     const unsigned char* __restrict__ defer) {
   __shared__ int keys[4][SPG_HS];
   __shared__ double hval[4][SPG_HS];
   __shared__ int list[4][SPG_MAXD];
@@ -1076,6 +1079,7 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= n) return;
+  if (defer && !defer[row]) return;       // done by k_spgemm_small
   const int total = spg_prefix(arp, acol, brp, row, lane, ja[w], pre[w]);
   const int base = crp[row], cnt = crp[row + 1] - base;
   if (cnt > SPG_MAXD) return;   // flagged by the count pass
@@ -1173,6 +1177,99 @@ __global__ __launch_bounds__(256) void k_spgemm_fill(int n, const int* __restric
   for (int t = lane; t < cnt; t += 64) {
     ccol[base + t] = list[w][t];
     cval[base + t] = lval[w][t];
+  }
+}
+// Short rows, G lanes per row (64 / G rows per wave): rows of A with at most G entries whose products number at most G
+// -- A P0 of a stencil matrix (7 products: G = 8, eight rows per wave), A P (about 25: G = 32), the first coarse level's
+// A P0 (31: G = 64).  One wave per row spent most of its time in per-row latency (prefix table and hash table in LDS,
+// dependent loads) with 7 of 64 lanes busy: 2.29 M rows of A P0 took 1.8 + 4.4 ms (count + fill).  Here everything lives in
+// registers: the B-row lengths are scanned with shuffles inside the group, lane p finds the entry its product belongs to,
+// the (column, product number) keys are sorted by a bitonic network inside the group, run heads fold their run from the
+// left (product order: the scans' sum order, bit-identical results) and write the row, already sorted.  Rows that do not fit
+// are marked in `defer` and left to the wave-per-row kernels (FILL pass: recomputed, same decision).
+template <int G, bool FILL>
+__global__ __launch_bounds__(256) void k_spgemm_small(int n, const int* __restrict__ arp, const int* __restrict__ acol,
+                                                      const double* __restrict__ aval, const int* __restrict__ brp,
+                                                      const int* __restrict__ bcol, const double* __restrict__ bval,
+                                                      int* __restrict__ cnt, const int* __restrict__ crp,
+                                                      int* __restrict__ ccol, double* __restrict__ cval,
+                                                      unsigned char* __restrict__ defer, int* __restrict__ flags) {
+  constexpr int RPW = 64 / G;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gl = lane % G, gbase = lane - gl;
+  const int row = (blockIdx.x * 4 + w) * RPW + lane / G;
+  const bool live = row < n;
+  const int a0 = live ? arp[row] : 0;
+  const int na = live ? arp[row + 1] - a0 : 0;
+  int b0 = 0, len = 0;
+  double av = 0.0;
+  if (gl < na && na <= G) {
+    const int j = acol[a0 + gl];
+    b0 = brp[j];
+    len = brp[j + 1] - b0;
+    if (FILL) av = aval[a0 + gl];
+  }
+  int incl = len;
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+    const int t = __shfl_up(incl, o, G);
+    if (gl >= o) incl += t;
+  }
+  const int total = __shfl(incl, G - 1, G);
+  const bool fits = na <= G && total <= G;
+  if (!FILL && live && gl == 0) {
+    defer[row] = fits ? 0 : 1;
+    if (!fits) atomicAdd(&flags[1], 1);
+  }
+  // product p = gl of the row: entry k of the A row with incl[k - 1] <= p < incl[k]
+  int k = 0;
+#pragma unroll
+  for (int q = 0; q < G; ++q) k += (__shfl(incl, q, G) <= gl) ? 1 : 0;
+  const bool has = fits && gl < total;
+  const int ks = has ? k : 0;
+  const int kb0 = __shfl(b0, ks, G);
+  const int kexcl = __shfl(incl - len, ks, G);
+  double kav = 0.0;
+  if (FILL) kav = __shfl(av, ks, G);
+  unsigned long long ck = ~0ull;
+  double v = 0.0;
+  if (has) {
+    const int l = kb0 + (gl - kexcl);
+    ck = ((unsigned long long)(unsigned)bcol[l] << 6) | (unsigned)gl;
+    if (FILL) v = kav * bval[l];
+  }
+#pragma unroll
+  for (int k2 = 2; k2 <= G; k2 <<= 1)
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const unsigned long long ock = __shfl_xor(ck, j, 64);
+      double ov = 0.0;
+      if (FILL) ov = __shfl_xor(v, j, 64);
+      const bool take_min = (((gl & j) == 0) == ((gl & k2) == 0));
+      const bool swap = take_min ? (ock < ck) : (ock > ck);
+      if (swap) { ck = ock; if (FILL) v = ov; }
+    }
+  const unsigned long long prev = __shfl_up(ck, 1, G);
+  const bool head = (ck != ~0ull) && (gl == 0 || (prev >> 6) != (ck >> 6));
+  const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
+  const unsigned long long heads = __ballot(head) & gmask;
+  if (!FILL) {
+    if (live && fits && gl == 0) cnt[row] = __builtin_popcountll(heads);
+    return;
+  }
+  double acc = 0.0 + v;                          // the scans start every sum at +0.0
+  for (int d = 1; d < G; ++d) {                  // left fold of each run into its head lane, in product order
+    const unsigned long long nk = __shfl_down(ck, d, G);
+    const double nv = __shfl_down(v, d, G);
+    const bool more = head && gl + d < G && (nk >> 6) == (ck >> 6);
+    if (more) acc += nv;
+    if (!__ballot(more)) break;
+  }
+  if (head) {
+    const int pos = __builtin_popcountll(heads & ((1ull << lane) - 1ull));
+    const int base = crp[row];
+    ccol[base + pos] = (int)(ck >> 6);
+    cval[base + pos] = acc;
   }
 }
 // rowptr[0..n] from the counts in rowptr[1..n]: inclusive scan on the device (round 2 took the counts to the host and back:
@@ -1281,20 +1378,50 @@ static void host_exclusive_scan(int* dcnt_to_ptr, int n, int64_t* total) {   // 
   if (run > 0x7fffffffLL) throw std::runtime_error("sparse product: more than 2^31 entries");
   *total = run;
 }
+static bool g_spgemm_small_host = true;     // host mirror of g_spgemm_no_small (validation switch "spgemm_small_rows")
 Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
   (void)ncols_b;
   Csr c;
   *ok = true;
   c.n = a.n;
   if (a.n == 0) return c;
-  int* dflag = (int*)alloc(sizeof(int));
+  int* dflag = (int*)alloc(2 * sizeof(int));          // [0] overflow, [1] rows the group pass left to the wave-per-row kernels
   c.rowptr = (int*)alloc(sizeof(int) * ((size_t)a.n + 1));
-  hipLaunchKernelGGL(k_spgemm_count, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, b.rowptr, b.col,
-                     c.rowptr + 1, dflag);
-  int hflag = 0;
-  d2h(&hflag, dflag, sizeof(int));
-  if (hflag) {
+  // lanes per row of the short-row pass, from the average row: most rows of a mesh-like matrix look like the average one
+  int G = 0;
+  if (g_spgemm_small_host && !g_spgemm_fill_scan && a.n >= 256 && b.n > 0) {
+    const double na = (double)a.nnz / a.n, est = na * ((double)b.nnz / b.n);
+    if (na <= 7.5 && est <= 7.5) G = 8;
+    else if (na <= 15.0 && est <= 14.0) G = 16;
+    else if (na <= 30.0 && est <= 26.0) G = 32;
+    else if (na <= 60.0 && est <= 52.0) G = 64;
+  }
+  unsigned char* defer = nullptr;
+#define SPG_SMALL(GG, FILL)                                                                                                  \
+  hipLaunchKernelGGL((k_spgemm_small<GG, FILL>), dim3((unsigned)((a.n + 256 / GG - 1) / (256 / GG))), dim3(256), 0, g_stream, \
+                     a.n, a.rowptr, a.col, a.val, b.rowptr, b.col, b.val, c.rowptr + 1, c.rowptr, c.col, c.val, defer, dflag)
+#define SPG_SMALL_G(FILL)                                      \
+  do {                                                         \
+    if (G == 8) SPG_SMALL(8, FILL);                            \
+    else if (G == 16) SPG_SMALL(16, FILL);                     \
+    else if (G == 32) SPG_SMALL(32, FILL);                     \
+    else SPG_SMALL(64, FILL);                                  \
+  } while (0)
+  int hflag[2] = {0, 0};
+  if (G) {
+    defer = (unsigned char*)alloc((size_t)a.n);
+    SPG_SMALL_G(false);
+    d2h(hflag, dflag, 2 * sizeof(int));
+  }
+  const bool general = !G || hflag[1] > 0;
+  if (general) {
+    hipLaunchKernelGGL(k_spgemm_count, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, b.rowptr, b.col,
+                       c.rowptr + 1, dflag, defer);
+    d2h(hflag, dflag, sizeof(int));
+  }
+  if (hflag[0]) {
     dfree(dflag);
+    dfree(defer);
     dfree(c.rowptr);
     *ok = false;
     return Csr();
@@ -1304,15 +1431,21 @@ Csr spgemm(const Csr& a, const Csr& b, int ncols_b, bool* ok) {
   c.nnz = total;
   c.col = (int*)alloc(sizeof(int) * std::max<size_t>(1, (size_t)total));
   c.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)total));
-  if (g_spgemm_fill_scan)
-    hipLaunchKernelGGL(k_spgemm_fill_scan, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
-                       b.col, b.val, c.rowptr, c.col, c.val, dflag);
-  else
-    hipLaunchKernelGGL(k_spgemm_fill, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
-                       b.col, b.val, c.rowptr, c.col, c.val, dflag);
-  d2h(&hflag, dflag, sizeof(int));
+  if (G) SPG_SMALL_G(true);
+  if (general) {
+    if (g_spgemm_fill_scan)
+      hipLaunchKernelGGL(k_spgemm_fill_scan, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
+                         b.col, b.val, c.rowptr, c.col, c.val, dflag);
+    else
+      hipLaunchKernelGGL(k_spgemm_fill, dim3((a.n + 3) / 4), dim3(256), 0, g_stream, a.n, a.rowptr, a.col, a.val, b.rowptr,
+                         b.col, b.val, c.rowptr, c.col, c.val, dflag, defer);
+    d2h(hflag, dflag, sizeof(int));
+  }
+#undef SPG_SMALL_G
+#undef SPG_SMALL
   dfree(dflag);
-  if (hflag) {
+  dfree(defer);
+  if (hflag[0]) {
     dfree(c.rowptr); dfree(c.col); dfree(c.val);
     *ok = false;
     return Csr();
@@ -4256,6 +4389,7 @@ bool set_variant(const char* name, int value) {
     lazy_init();
     const int off = value ? 0 : 1;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_spgemm_no_small), &off, sizeof(int)));
+    g_spgemm_small_host = value != 0;
     return true;
   }
   return false;

@@ -50,6 +50,7 @@ PY
     rm -rf /tmp/trace_$TAG
     (cd /tmp && timeout -k 10 ${LIMIT:-600} rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$TAG -o run -- python3 $R/bench.py "$@" > $O/${TAG}_trace.json 2> $O/${TAG}_trace.err); rc=$?
     f=$(find /tmp/trace_$TAG -name "*kernel_trace.csv" | head -1)
+    [ -n "$f" ] && [ -n "$GAPS" ] && python3 scripts/trace_gaps.py $f $GAPS > $O/${TAG}_gaps.txt
     [ -n "$f" ] && python3 scripts/trace_window.py $f "$anchor" $occ $cnt > $O/${TAG}_window.txt && tail -3 $O/${TAG}_window.txt; [ -n "$f" ] && [ -n "$ANCHORB" ] && python3 scripts/trace_window.py $f "$ANCHORB" 0 0 > $O/${TAG}_intervals.txt
     exit $rc ;;
   spmm)

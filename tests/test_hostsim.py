@@ -57,6 +57,18 @@ def test_multilevel_amg_inner_preconditioner(lib):
     assert amg["dls1_iterations"] * 3 < jac["dls1_iterations"]
 
 
+def test_threaded_aggregation_gives_the_serial_aggregates(lib, monkeypatch):
+    """Aggregation with its strong-neighbour lists and its leftover pass in row ranges on several host threads (what one
+    big subdomain per GPU gets) == the one-thread walk: same hierarchy sizes, same inner and outer iteration counts."""
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.19", "-geneo_cut", "8", "-ksp_type", "cg", "-amg_coarse_size", "100"] + TIGHT
+    _, one = cases.compare_with_oracle(lib, 20, (2, 2, 2), 1, argv)
+    monkeypatch.setenv("GENEO_AGG_THREADS", "3")
+    monkeypatch.setenv("GENEO_AGG_MIN_NNZ", "0")
+    _, three = cases.compare_with_oracle(lib, 20, (2, 2, 2), 1, argv)
+    for key in ("amg_levels", "amg_operator_complexity", "dls1_iterations", "eig_iterations", "dimE"):
+        assert one[key] == three[key], key
+
+
 def test_config0_laplacian_2d_two_subdomains_five_vectors(lib):
     """BASELINE configs[0]: tst/laplacian 2-D stencil, 2 subdomains, 5 eigenvectors per subdomain."""
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "5", "-ksp_type", "gmres"] + TIGHT
