@@ -2090,6 +2090,18 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
   const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
   const int cb = base ? base[s] : 0;     // 16-bit columns are offsets from the slice's lowest column
   const double* __restrict__ xin = (EPI == EPI_PRE) ? b : x;
+  // The epilogue's own operands do not depend on the product: their loads are issued HERE, in front of the matrix stream,
+  // instead of after the last gather has come back (one dependent memory round trip less per wave; a wave holds one
+  // 64-row slice, so its run time is a chain of round trips, not bandwidth).  Same arithmetic, same results.
+  const int r = 64 * s + l;
+  const bool rok = r < n && (WPS == 1 || wv == 0);
+  double e_b = 0.0, e_z = 0.0, e_d = 0.0, e_x = 0.0;
+  if (rok) {
+    if (EPI == EPI_RES || EPI == EPI_JAC || EPI == EPI_POST || EPI == EPI_PRE) e_b = b[r];
+    if (EPI == EPI_ADD || EPI == EPI_POST) e_z = z[r];
+    if (EPI == EPI_JAC || EPI == EPI_POST || (EPI == EPI_PRE && z)) e_d = dinv[r];
+    if (EPI == EPI_JAC) e_x = x[r];
+  }
   constexpr int STEP = 64 * WPS;
   double acc[UNR];
 #pragma unroll
@@ -2117,22 +2129,20 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
     if (wv > 0) return;
     sum = (sum + part[0][l]) + (part[1][l] + part[2][l]);
   }
-  const int r = 64 * s + l;
   if (r >= n) return;
   if (EPI == EPI_NONE) {
     y[r] = sum;
   } else if (EPI == EPI_RES) {
-    y[r] = b[r] - sum;
+    y[r] = e_b - sum;
   } else if (EPI == EPI_ADD) {
-    y[r] = z[r] + sum;
+    y[r] = e_z + sum;
   } else if (EPI == EPI_JAC) {
-    y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+    y[r] = e_x + w * e_d * (e_b - sum);
   } else if (EPI == EPI_POST) {
-    y[r] = w * dinv[r] * (z[r] + b[r]) + sum;
+    y[r] = w * e_d * (e_z + e_b) + sum;
   } else {  // EPI_PRE
-    const double bb = b[r];
-    if (z) z[r] = w * dinv[r] * bb;
-    y[r] = bb - w * sum;
+    if (z) z[r] = w * e_d * e_b;
+    y[r] = e_b - w * sum;
   }
 }
 template <int EPI>

@@ -161,6 +161,7 @@ class PC {
   std::vector<int> Epiv;
   bool E_chol = true;
   std::vector<double> h_yE;
+  std::vector<double> h_Dscratch;   // partition of unity on the host, reused by the next set-up
   double cheb_lmax = 2.0, cheb_lmax1 = 2.0;
   struct Amg1Pending;
   std::unique_ptr<Amg1Pending> pend1;   // level-1 hierarchy whose host set-up is still running
