@@ -277,6 +277,13 @@ const char* spmv_kernel_name();
 void  set_mfma(bool enable);   // false: run the plain-FMA twins of the MFMA kernels (validation)
 // validation switches between two device forms of the same arithmetic ("spgemm_fill_scan", "gram_flat"); false: unknown name
 bool  set_variant(const char* name, int value);
+// Page-locked host memory for the small per-iteration transfers of LOBPCG (Gram rows down, Rayleigh-Ritz coefficients up):
+// a copy to or from it is ONE DMA; from pageable memory the runtime stages it in pieces and synchronises in between.
+void* pinned_alloc(size_t bytes);
+void  pinned_free(void* p);
+// stream-ordered upload from pinned memory, NO synchronisation: the source must stay untouched until the calling thread's
+// stream has been synchronised (or has passed a later synchronous copy)
+void  h2d_async(void* d, const void* h_pinned, size_t bytes);
 int   selftest_mfma_f64();   // 0 = the f64 MFMA operand/result lane maps are as the kernels assume
 void* event_create();
 // device-to-host copy on a side stream as soon as `event` (recorded on the library stream) has completed: the library

@@ -385,6 +385,19 @@ void d2h(void* h, const void* d, size_t bytes) {
   HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
 }
+void* pinned_alloc(size_t bytes) {
+  bind_thread();
+  void* p = nullptr;
+  HIPCHK(hipHostMalloc(&p, std::max<size_t>(bytes, 8), hipHostMallocDefault));
+  return p;
+}
+void pinned_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+void h2d_async(void* d, const void* h_pinned, size_t bytes) {
+  if (!bytes) return;
+  HIPCHK(hipMemcpyAsync(d, h_pinned, bytes, hipMemcpyHostToDevice, g_stream));
+}
 void d2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
@@ -1773,6 +1786,15 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
   if (t >= nwb || s >= nslice) return;
   const int l = threadIdx.x & 63;
   const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
+  // the epilogue's own operands, loaded in front of the matrix stream (see k_spmv_sell_lp)
+  const int r = 64 * s + l;
+  double e_b = 0.0, e_z = 0.0, e_d = 0.0, e_x = 0.0;
+  if (r < n) {
+    if (EPI == EPI_RES || EPI == EPI_JAC || EPI == EPI_POST || EPI == EPI_PRE) e_b = b[r];
+    if (EPI == EPI_ADD || EPI == EPI_POST) e_z = z[r];
+    if (EPI == EPI_JAC || EPI == EPI_POST || (EPI == EPI_PRE && z)) e_d = dinv[r];
+    if (EPI == EPI_JAC) e_x = x[r];
+  }
   double acc[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
@@ -1796,20 +1818,18 @@ __global__ __launch_bounds__(256) void k_spmv_sell_epi(const int64_t* __restrict
   double sum = acc[0];
 #pragma unroll
   for (int u = 1; u < UNR; ++u) sum += acc[u];
-  const int r = 64 * s + l;
   if (r >= n) return;
   if (EPI == EPI_RES) {
-    y[r] = b[r] - sum;
+    y[r] = e_b - sum;
   } else if (EPI == EPI_ADD) {
-    y[r] = z[r] + sum;
+    y[r] = e_z + sum;
   } else if (EPI == EPI_JAC) {
-    y[r] = x[r] + w * dinv[r] * (b[r] - sum);
+    y[r] = e_x + w * e_d * (e_b - sum);
   } else if (EPI == EPI_POST) {
-    y[r] = w * dinv[r] * (z[r] + b[r]) + sum;
+    y[r] = w * e_d * (e_z + e_b) + sum;
   } else {  // EPI_PRE
-    const double bb = b[r];
-    if (z) z[r] = w * dinv[r] * bb;
-    y[r] = bb - w * sum;
+    if (z) z[r] = w * e_d * e_b;
+    y[r] = e_b - w * sum;
   }
 }
 // Wide slices (coarse Galerkin operators, restrictions: 30-60 entries per row on a few thousand slices): with one wave
@@ -2484,6 +2504,21 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
           default: break;
         }
       }
+      // the epilogue's own rows (loading them in front of the gathers was measured: same time, 24 more registers)
+      d2 e_b[U], e_z[U], e_x[U];
+      double e_d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
+        e_b[u] = e_z[u] = e_x[u] = d2{0.0, 0.0};
+        e_d[u] = 0.0;
+        if (EPI != EPI_NONE && r < n) {
+          if (EPI == EPI_RES || EPI == EPI_JAC || EPI == EPI_POST || EPI == EPI_PRE) e_b[u] = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
+          if (EPI == EPI_ADD || EPI == EPI_POST) e_z[u] = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q);
+          if (EPI == EPI_JAC) e_x[u] = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q);
+          if (EPI == EPI_JAC || EPI == EPI_POST || (EPI == EPI_PRE && Z)) e_d[u] = dinv[r];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
@@ -2494,19 +2529,16 @@ __global__ __launch_bounds__(256) void k_spmm_sell(const int64_t* __restrict__ s
         if (EPI == EPI_NONE) {
           out = a2;
         } else if (EPI == EPI_RES) {
-          out = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2;
+          out = e_b[u] - a2;
         } else if (EPI == EPI_ADD) {
-          out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) + a2;
+          out = e_z[u] + a2;
         } else if (EPI == EPI_JAC) {
-          out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
-                (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+          out = e_x[u] + (w * e_d[u]) * (e_b[u] - a2);
         } else if (EPI == EPI_POST) {
-          out = (w * dinv[r]) * (*reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
-                                 *reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
+          out = (w * e_d[u]) * (e_z[u] + e_b[u]) + a2;
         } else {  // EPI_PRE: X = B, pre = dinv
-          const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
-          if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
-          out = bb - w * a2;
+          if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * e_d[u]) * e_b[u];
+          out = e_b[u] - w * a2;
         }
         __builtin_nontemporal_store(out, reinterpret_cast<d2*>(Y + r * ldy + 2 * q));
       }
@@ -2542,6 +2574,28 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
 #pragma unroll
   for (int u = 0; u < U; ++u) acc[u] = d2{0.0, 0.0};
   const int rl0 = 16 * wave + grp;
+  // The epilogue's own rows do not depend on the product.  For the zero-guess sweep (PRE: one operand) they are loaded in
+  // front of the gathers (first coarse level: 209 -> 191 us); for JAC and POST the three operands of four row groups cost
+  // 110 registers and half the resident waves (POST: 578 -> 800 us): every other epilogue loads them behind the
+  // accumulation as before.
+  constexpr bool EARLY = (EPI == EPI_PRE);
+  d2 e_b[U], e_z[U], e_x[U];
+  double e_d[U];
+  auto load_epi = [&]() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = (int64_t)64 * s + 16 * wave + u * RS + grp;
+      e_b[u] = e_z[u] = e_x[u] = d2{0.0, 0.0};
+      e_d[u] = 0.0;
+      if (EPI != EPI_NONE && r < n) {
+        if (EPI == EPI_RES || EPI == EPI_JAC || EPI == EPI_POST || EPI == EPI_PRE) e_b[u] = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
+        if (EPI == EPI_ADD || EPI == EPI_POST) e_z[u] = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q);
+        if (EPI == EPI_JAC) e_x[u] = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q);
+        if (EPI == EPI_JAC || EPI == EPI_POST || (EPI == EPI_PRE && Z)) e_d[u] = dinv[r];
+      }
+    }
+  };
+  if (EARLY) load_epi();
   for (int k0 = 0; k0 < wd; k0 += KC) {
     const int kc = (wd - k0 < KC) ? wd - k0 : KC;
     if (k0 > 0) __syncthreads();
@@ -2571,6 +2625,7 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
       }
     }
   }
+  if (!EARLY) load_epi();
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t r = (int64_t)64 * s + 16 * wave + u * RS + grp;
@@ -2581,19 +2636,16 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
     if (EPI == EPI_NONE) {
       out = a2;
     } else if (EPI == EPI_RES) {
-      out = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2;
+      out = e_b[u] - a2;
     } else if (EPI == EPI_ADD) {
-      out = *reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) + a2;
+      out = e_z[u] + a2;
     } else if (EPI == EPI_JAC) {
-      out = *reinterpret_cast<const d2*>(X + r * ldx + 2 * q) +
-            (w * dinv[r]) * (*reinterpret_cast<const d2*>(B + r * ldb + 2 * q) - a2);
+      out = e_x[u] + (w * e_d[u]) * (e_b[u] - a2);
     } else if (EPI == EPI_POST) {
-      out = (w * dinv[r]) * (*reinterpret_cast<const d2*>(Z + r * ldz + 2 * q) +
-                             *reinterpret_cast<const d2*>(B + r * ldb + 2 * q)) + a2;
+      out = (w * e_d[u]) * (e_z[u] + e_b[u]) + a2;
     } else {  // EPI_PRE: X = B, pre = dinv
-      const d2 bb = *reinterpret_cast<const d2*>(B + r * ldb + 2 * q);
-      if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * dinv[r]) * bb;
-      out = bb - w * a2;
+      if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * e_d[u]) * e_b[u];
+      out = e_b[u] - w * a2;
     }
     *reinterpret_cast<d2*>(Y + r * ldy + 2 * q) = out;
   }

@@ -1500,8 +1500,23 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   auto applyA = [&](const double* X, double* Y) { bk::spmm_strided(*P.A, X, p3, Y, p3, m, P.As, P.As); info.eig_spmm++; };
   auto applyB = [&](const double* X, double* Y) { bk::spmm_strided(*P.B, X, p3, Y, p3, m, P.Bs, P.Bs); info.eig_spmm++; };
 
-  std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3), hC((size_t)ns * p3 * 2 * m);
-  std::vector<double> hGw((size_t)ns * 2 * m * p3);   // W rows of both Gram matrices: [(A W)^T S ; (B W)^T S] per subdomain
+  std::vector<double> hGA((size_t)ns * p3 * p3), hGB((size_t)ns * p3 * p3);
+  // what moves between host and device in EVERY iteration lives in page-locked memory (one DMA per copy, uploads without a
+  // host synchronisation): the Rayleigh-Ritz coefficients, keep / lam of the fused update, the W rows of the Gram matrices
+  struct Pinned {
+    double* p = nullptr;
+    size_t n = 0;
+    explicit Pinned(size_t count) : p((double*)bk::pinned_alloc(sizeof(double) * std::max<size_t>(1, count))), n(count) {
+      std::fill(p, p + n, 0.0);
+    }
+    ~Pinned() { bk::pinned_free(p); }
+    Pinned(const Pinned&) = delete;
+    Pinned& operator=(const Pinned&) = delete;
+    double* data() { return p; }
+    double* begin() { return p; }
+  };
+  Pinned hC((size_t)ns * p3 * 2 * m), hKL((size_t)ns * 2 * m);
+  Pinned hGw((size_t)ns * 2 * m * p3);   // W rows of both Gram matrices: [(A W)^T S ; (B W)^T S] per subdomain
   bool have_prop = false;
   bool fused_update = false;  // set below, once the convergence test is known (m = 32, shift-invert test, MFMA on)
   bool have_R = false;        // the residual block of the current X is already in `cr` (written by the fused update)
@@ -1680,12 +1695,18 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     t_rr_host += secs(tg1, clk::now());
     const size_t co = (size_t)s0 * p * qout, mo = (size_t)s0 * m;    // the group's offsets in the per-subdomain arrays
-    bk::h2d(dC + co, hC.data() + co, sizeof(double) * (size_t)(s1 - s0) * p * qout);
+    // stream-ordered uploads from pinned memory, no host synchronisation: the host next writes these arrays in the next
+    // Rayleigh-Ritz of the same group, which follows a synchronous download behind the kernels that read them
+    bk::h2d_async(dC + co, hC.data() + co, sizeof(double) * (size_t)(s1 - s0) * p * qout);
     if (fused_update && p == p3 && with_p) {
       // one launch: [X' P'] for S, A S, B S (the [P W] product once per operand) and the next residual block
       for (size_t e = mo; e < (size_t)s1 * m; ++e) keep[e] = (locked[e] || frozen[e / m]) ? 0.0 : 1.0;
-      bk::h2d(dkeep + mo, keep.data() + mo, sizeof(double) * (size_t)(s1 - s0) * m);
-      bk::h2d(dlam + mo, lam.data() + mo, sizeof(double) * (size_t)(s1 - s0) * m);
+      double* hk = hKL.data() + mo;
+      double* hl = hKL.data() + (size_t)ns * m + mo;
+      std::copy(keep.begin() + mo, keep.begin() + (size_t)s1 * m, hk);
+      std::copy(lam.begin() + mo, lam.begin() + (size_t)s1 * m, hl);
+      bk::h2d_async(dkeep + mo, hk, sizeof(double) * (size_t)(s1 - s0) * m);
+      bk::h2d_async(dlam + mo, hl, sizeof(double) * (size_t)(s1 - s0) * m);
       bk::lobpcg_update32(*cg, S, AS, BS, dC + co, dkeep + mo, dlam + mo, dmask + mo, T, AT, BT, cr);
       if (last) have_R = true;
     } else {

@@ -560,6 +560,9 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
 }
 void set_mfma(bool) {}
 bool set_variant(const char*, int) { return false; }
+void* pinned_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 8); }
+void pinned_free(void* p) { std::free(p); }
+void h2d_async(void* d, const void* h, size_t bytes) { if (bytes) std::memcpy(d, h, bytes); }
 void set_spmv_kind(int) {}
 const char* spmv_kernel_name() { return "hostsim"; }
 int selftest_mfma_f64() { return 0; }
