@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96",
+KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96", "k_gram_flat": "gram96",
            "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32": "lobpcg_update32"}
 CALIB = 40_000_000
 
