@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 FP64_MFMA_PEAK_TFS = 78.6  # AMD MI355X datasheet FP64 matrix (the guide's table has no FP64-MFMA row); DESIGN.md section 3
 KERNEL_CLASSES = [(0, "k_spmv_sell (fine-level CSR SpMV)", "hbm"), (1, "k_spmm_sell (fine-level SpMM, 32 columns)", "hbm"),
                   (2, "k_gram_flat (Rayleigh-Ritz Gram, FP64 MFMA; k_gram_mfma for other shapes)", "mfma"),
-                  (3, "k_lobpcg_update32 (fused LOBPCG block update of S, A S, B S + residual, FP64 MFMA)", "mfma"),
+                  (3, "k_lobpcg_update32 (LOBPCG block update [X' P'] = S C, FP64 MFMA; lean iteration: S alone, the residual comes from the two-operator SpMM)", "mfma"),
                   (4, "k_spmv_sell_lp (V-cycle of the local solves: fine-level passes over the float / 16-bit-column companions)", "hbm")]
 
 

@@ -150,6 +150,8 @@ SYMBOLS = {
     "GeneoSpmmFused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_double]),
     "GeneoSpmmDualTest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "GeneoSpmmDualResidualTest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  c_int_p, c_dbl_p, c_dbl_p]),
     "GeneoSpmvFusedSingle": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_double]),
     "GeneoTestLobpcgUpdate": (C.c_int, [C.c_int, c_int_p] + [c_dbl_p] * 11),

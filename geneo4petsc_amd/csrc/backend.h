@@ -126,6 +126,11 @@ double* sell_values_on(const Csr& a, const Csr& b);
 bool spmm_dual_available(const Csr& a, int m);
 void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* Y1, double* Y2, int ldy,
                int m);
+struct Chunks;
+// R = mask .* ((a's pattern, v1) X - (a's pattern, v2) X diag(lam)) per subdomain of c (lam, mask: nsub x m): LOBPCG's
+// residual block straight from X, neither product written (R: n x m with leading dimension ldr)
+void spmm_dual_residual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* R, int ldr,
+                        int m, const Chunks& c, const double* lam, const double* mask);
 // Fused epilogues of the multigrid cycle (one launch instead of SpMV + 1-2 vector kernels); blocks are
 // row-major with m columns, m = 1 runs the sliced SpMV kernel.  A must be square for JAC / PRE.
 //   EPI_RES : Y = B - A X
@@ -232,6 +237,8 @@ void block_residual_norms(const Chunks& c, const double* AX, int lda, const doub
 void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const double* BS, const double* C,
                      const double* keep, const double* lam, const double* mask, double* T, double* AT, double* BT,
                      double* R);
+// the basis part of it alone: columns 0..63 of T = [X' P'] from S (the "lean" iteration carries no A S / B S)
+void lobpcg_update32_basis(const Chunks& c, const double* S, const double* C, const double* keep, double* T);
 bool lobpcg_update32_available();
 void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m);
 // Y = a * d .* X + b * Y  (row scaling by d[i])

@@ -2728,12 +2728,17 @@ __device__ __forceinline__ void spmm_sell_accum2(const int* mc, const double* mv
       acc2[u] += mv2[k * 64 + rl0 + u * RS] * x[k][u];
     }
 }
-template <int LG, int U>
+// RES = 1: instead of the two products the kernel writes the LOBPCG residual block of X,
+//     Y1[r, j] = mask[s, j] (A1 X - A2 X diag(lam_s))[r, j]      (s = subdomain of row r, found in suboff[0 .. nsub]),
+// so that neither product travels through HBM (Y2 is not touched).
+template <int LG, int U, int RES>
 __global__ __launch_bounds__(256) void k_spmm_sell_dual(const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
                                                         const double* __restrict__ v1, const double* __restrict__ v2, int n,
                                                         const int* __restrict__ sched, const int* __restrict__ xptr,
                                                         const double* __restrict__ X, int ldx, double* __restrict__ Y1,
-                                                        double* __restrict__ Y2, int ldy) {
+                                                        double* __restrict__ Y2, int ldy, const int* __restrict__ suboff,
+                                                        int nsub, const double* __restrict__ lam,
+                                                        const double* __restrict__ mask) {
   typedef spmm_d2 d2;
   constexpr int KC = 8;
   constexpr int RS = 64 / LG;
@@ -2789,8 +2794,23 @@ __global__ __launch_bounds__(256) void k_spmm_sell_dual(const int64_t* __restric
       for (int u = 0; u < U; ++u) {
         const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
         if (r >= n) continue;
-        __builtin_nontemporal_store(acc1[u], reinterpret_cast<d2*>(Y1 + r * ldy + 2 * q));
-        __builtin_nontemporal_store(acc2[u], reinterpret_cast<d2*>(Y2 + r * ldy + 2 * q));
+        if (RES) {
+          int lo = 0, hi = nsub;                    // largest lo with suboff[lo] <= r
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (suboff[mid] <= r) lo = mid; else hi = mid;
+          }
+          constexpr int mcols = 2 * LG;
+          const d2 lm = *reinterpret_cast<const d2*>(lam + lo * mcols + 2 * q);
+          const d2 mk = *reinterpret_cast<const d2*>(mask + lo * mcols + 2 * q);
+          d2 res;
+          res.x = mk.x * (acc1[u].x - lm.x * acc2[u].x);
+          res.y = mk.y * (acc1[u].y - lm.y * acc2[u].y);
+          __builtin_nontemporal_store(res, reinterpret_cast<d2*>(Y1 + r * ldy + 2 * q));
+        } else {
+          __builtin_nontemporal_store(acc1[u], reinterpret_cast<d2*>(Y1 + r * ldy + 2 * q));
+          __builtin_nontemporal_store(acc2[u], reinterpret_cast<d2*>(Y2 + r * ldy + 2 * q));
+        }
       }
     }
   }
@@ -2809,11 +2829,35 @@ void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X
   int wpx = g_spmm_wpx < 0 ? 64 : (g_spmm_wpx == 0 ? 64 : g_spmm_wpx);
   const int need = (a.nslice + 31) / 32;
   if (wpx > need) wpx = need < 1 ? 1 : need;
-#define DUAL(L)                                                                                                                hipLaunchKernelGGL((k_spmm_sell_dual<L, 2>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, v1, v2, a.n, a.sched,                      a.xcd_ptr, X, ldx, Y1, Y2, ldy)
+#define DUAL(L)                                                                                                   \
+  hipLaunchKernelGGL((k_spmm_sell_dual<L, 2, 0>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, v1, v2, a.n,  \
+                     a.sched, a.xcd_ptr, X, ldx, Y1, Y2, ldy, (const int*)nullptr, 0, (const double*)nullptr,            \
+                     (const double*)nullptr)
   if (m == 16) DUAL(8);
   else if (m == 32) DUAL(16);
   else DUAL(32);
 #undef DUAL
+}
+// R = mask .* (A1 X - A2 X diag(lam)) per subdomain of c, both products in one pass over X and neither written (LOBPCG's
+// residual block from X alone; lam / mask: nsub x m, subdomain-major).  Same accumulation order as spmm_dual.
+void spmm_dual_residual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* R, int ldr,
+                        int m, const Chunks& c, const double* lam, const double* mask) {
+  if (a.n == 0) return;
+  if (!spmm_dual_available(a, m) || (ldx & 1) || (ldr & 1) || !aligned16(X) || !aligned16(R) || !aligned16(lam) || !aligned16(mask))
+    throw std::runtime_error("spmm_dual_residual: operands not on the sliced path");
+  if (c.n != a.n) throw std::runtime_error("spmm_dual_residual: the subdomain list does not cover the matrix rows");
+  ProfScope prof(PROF_SPMM, a.fine && m >= 16, (double)a.nnz * 20.0 + (double)a.n * 4.0 + 16.0 * m * (double)a.n,
+                 4.0 * (double)a.nnz * m);
+  int wpx = g_spmm_wpx < 0 ? 64 : (g_spmm_wpx == 0 ? 64 : g_spmm_wpx);
+  const int need = (a.nslice + 31) / 32;
+  if (wpx > need) wpx = need < 1 ? 1 : need;
+#define DUALR(L)                                                                                                  \
+  hipLaunchKernelGGL((k_spmm_sell_dual<L, 2, 1>), dim3(8 * wpx), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, v1, v2, a.n,  \
+                     a.sched, a.xcd_ptr, X, ldx, R, (double*)nullptr, ldr, c.suboff, c.nsub, lam, mask)
+  if (m == 16) DUALR(8);
+  else if (m == 32) DUALR(16);
+  else DUALR(32);
+#undef DUALR
 }
 // values of b laid out on the sliced pattern of a: out[e] = b(r, a.sl_col[e]) for the stored entries of row r of a, 0 for a's
 // entries b lacks and for the padding; *missing counts the entries of b that a's pattern does not hold
@@ -3890,6 +3934,9 @@ void block_mul(const Chunks& c, const double* S, int lds_, int p, const double* 
 // (next slab's loads in flight during the MFMA phase); the C fragments (24 doubles per lane) stay in registers.
 // Lane maps as k_blockmul_mfma.  Bytes: reads 3 x 96 n, writes 3 x 64 n + 32 n doubles = 4.0 KB per row (separate
 // kernels: 3 x (96 + 64) + (64 + 32) = 4.6 KB); flops 2 n (64 x 32 + 32 x 32) x 3.
+// NOPS = 1 (round 3, the "lean" iteration of core.cpp): only S is carried -- A X', B X' are never formed, the residual
+// comes from one two-operator product over X' (k_spmm_sell_dual<.., .., 1>) -- 1.28 KB per row instead of 4.0.
+template <int NOPS>
 __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                         const int* __restrict__ csub, const double* __restrict__ S,
                                                         const double* __restrict__ AS, const double* __restrict__ BS,
@@ -3927,20 +3974,20 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
   }
   d2 rg[NU];
   auto load_slab = [&](int t) {        // t = 3 * slab + operand
-    const int r = (t / 3) * SR;
+    const int r = (t / NOPS) * SR;
     const int nr = (nrows - r < SR) ? nrows - r : SR;
-    const d2* base = reinterpret_cast<const d2*>(src[t % 3] + (int64_t)(row0 + r) * p);
+    const d2* base = reinterpret_cast<const d2*>(src[t % NOPS] + (int64_t)(row0 + r) * p);
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       const int u = tid + 256 * j;
       rg[j] = (u < nr * (p / 2)) ? __builtin_nontemporal_load(base + u) : d2{0.0, 0.0};
     }
   };
-  const int nt = 3 * ((nrows + SR - 1) / SR);
+  const int nt = NOPS * ((nrows + SR - 1) / SR);
   load_slab(0);
   d4 ax = (d4){0.0, 0.0, 0.0, 0.0};
   for (int t = 0; t < nt; ++t) {
-    const int op = t % 3, r = (t / 3) * SR;
+    const int op = t % NOPS, r = (t / NOPS) * SR;
     const int nr = (nrows - r < SR) ? nrows - r : SR;
     __syncthreads();
 #pragma unroll
@@ -3968,8 +4015,8 @@ __global__ __launch_bounds__(256) void k_lobpcg_update32(const int* __restrict__
         const int rr = 16 * rt + (l >> 4) + 4 * v;
         if (rr < nr) __builtin_nontemporal_store(acc[v], out + (int64_t)(row0 + r + rr) * p + col);
       }
-      if (op == 1) ax = acc;
-      if (op == 2) {
+      if (NOPS == 3 && op == 1) ax = acc;
+      if (NOPS == 3 && op == 2) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int rr = 16 * rt + (l >> 4) + 4 * v;
@@ -3986,8 +4033,15 @@ void lobpcg_update32(const Chunks& c, const double* S, const double* AS, const d
   if (!aligned16(S) || !aligned16(AS) || !aligned16(BS)) throw std::runtime_error("lobpcg_update32: operands must be 16-byte aligned");
   // counted with the block updates it replaces (three of them): same class, bytes and flops of the fused form
   ProfScope prof(PROF_BLOCKMUL, true, 8.0 * (double)c.n * (3 * 96 + 3 * 64 + 32), 2.0 * (double)c.n * (64 * 32 + 32 * 32) * 3);
-  hipLaunchKernelGGL(k_lobpcg_update32, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, AS, BS, C, keep,
+  hipLaunchKernelGGL(k_lobpcg_update32<3>, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, AS, BS, C, keep,
                      lam, mask, T, AT, BT, R);
+}
+void lobpcg_update32_basis(const Chunks& c, const double* S, const double* C, const double* keep, double* T) {
+  if (c.nchunk == 0) return;
+  if (!aligned16(S)) throw std::runtime_error("lobpcg_update32_basis: operand must be 16-byte aligned");
+  ProfScope prof(PROF_BLOCKMUL, true, 8.0 * (double)c.n * (96 + 64), 2.0 * (double)c.n * (64 * 32 + 32 * 32));
+  hipLaunchKernelGGL(k_lobpcg_update32<1>, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, S, S, S, C, keep,
+                     keep, (const double*)nullptr, T, T, T, (double*)nullptr);
 }
 bool lobpcg_update32_available() { return !g_no_mfma; }
 

@@ -632,6 +632,27 @@ PetscErrorCode GeneoSpmmDualTest(GeneoSpmv a, GeneoSpmv b, const double* X, int 
   GUARD_END((PC) nullptr)
   return 0;
 }
+// R = mask .* (A X - B X diag(lam)) per subdomain (suboff: nsub + 1 first rows; lam, mask: nsub x m host arrays), both
+// products in one pass over X and neither written (bk::spmm_dual_residual: the residual block of LOBPCG's lean iteration)
+PetscErrorCode GeneoSpmmDualResidualTest(GeneoSpmv a, GeneoSpmv b, const double* X, int ldx, double* R, int ldr, int m,
+                                         int nsub, const int* suboff, const double* lam, const double* mask) {
+  if (!a || !b) return 1;
+  GUARD_BEGIN
+  if (!bk::spmm_dual_available(a->a, m)) return 2;
+  double* v = bk::sell_values_on(a->a, b->a);
+  if (!v) return 2;
+  bk::Chunks c = bk::chunks_upload(nsub, suboff);
+  double* dl = (double*)bk::alloc(sizeof(double) * (size_t)nsub * m);
+  double* dm = (double*)bk::alloc(sizeof(double) * (size_t)nsub * m);
+  bk::h2d(dl, lam, sizeof(double) * (size_t)nsub * m);
+  bk::h2d(dm, mask, sizeof(double) * (size_t)nsub * m);
+  bk::spmm_dual_residual(a->a, a->a.sl_val, v, X, ldx, R, ldr, m, c, dl, dm);
+  bk::sync();
+  bk::dfree(v); bk::dfree(dl); bk::dfree(dm);
+  bk::chunks_free(c);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
 PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X, double* Y, const double* B, double* Z,
                                     const double* dinv, double w) {
   if (!h) return 1;
@@ -680,6 +701,14 @@ PetscErrorCode GeneoTestLobpcgUpdate(int nsub, const int* suboff, const double* 
     return d;
   };
   const size_t nb = (size_t)n * 96;
+  if (!AS) {   // the basis-only form of the lean iteration: T = [X' P'] from S (AS, BS, lam, mask, AT, BT, R unused)
+    double *dS = up(S, nb), *dC = up(C, (size_t)nsub * 96 * 64), *dk = up(keep, (size_t)nsub * 32), *dT = up(nullptr, nb);
+    bk::lobpcg_update32_basis(c, dS, dC, dk, dT);
+    bk::d2h(T, dT, sizeof(double) * nb);
+    for (double* d : {dS, dC, dk, dT}) bk::dfree(d);
+    bk::chunks_free(c);
+    return 0;
+  }
   double *dS = up(S, nb), *dAS = up(AS, nb), *dBS = up(BS, nb), *dC = up(C, (size_t)nsub * 96 * 64);
   double *dk = up(keep, (size_t)nsub * 32), *dl = up(lam, (size_t)nsub * 32), *dm = up(mask, (size_t)nsub * 32);
   double *dT = up(nullptr, nb), *dAT = up(nullptr, nb), *dBT = up(nullptr, nb), *dR = up(nullptr, (size_t)n * 32);

@@ -1520,6 +1520,13 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   bool have_prop = false;
   bool fused_update = false;  // set below, once the convergence test is known (m = 32, shift-invert test, MFMA on)
   bool have_R = false;        // the residual block of the current X is already in `cr` (written by the fused update)
+  // "Lean" iteration (round 3, default where A and B share a sliced pattern): A S and B S are NOT carried.  With the Gram
+  // blocks of [X P] propagated on the host, the only consumers of A X, B X, A P, B P were the recurrences that produce
+  // them and the residual A X - B X diag(lam); the residual now comes from one two-operator product over X'
+  // (bk::spmm_dual_residual: both products in registers, only R written) and the update moves S alone: 1.28 + 0.6 KB per
+  // row and iteration instead of 4.0.  The residual is the true one in every iteration (no recurrence drift); the explicit
+  // 96 x 96 Gram refresh computes A [X P], B [X P] when it needs them.
+  bool lean = false;
   std::vector<double> keep((size_t)ns * m, 1.0);
   double* dkeep = nullptr;    // allocated below with the other per-pair device arrays
   static const bool full_gram = getenv("GENEO_LOBPCG_FULL_GRAM") != nullptr;   // experiment: explicit 96 x 96 Grams always
@@ -1707,8 +1714,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       std::copy(lam.begin() + mo, lam.begin() + (size_t)s1 * m, hl);
       bk::h2d_async(dkeep + mo, hk, sizeof(double) * (size_t)(s1 - s0) * m);
       bk::h2d_async(dlam + mo, hl, sizeof(double) * (size_t)(s1 - s0) * m);
-      bk::lobpcg_update32(*cg, S, AS, BS, dC + co, dkeep + mo, dlam + mo, dmask + mo, T, AT, BT, cr);
-      if (last) have_R = true;
+      if (lean) bk::lobpcg_update32_basis(*cg, S, dC + co, dkeep + mo, T);
+      else bk::lobpcg_update32(*cg, S, AS, BS, dC + co, dkeep + mo, dlam + mo, dmask + mo, T, AT, BT, cr);
+      if (last) have_R = true;   // lean: nothing left for the host to do -- the device phase starts with the residual product
     } else {
       if (s0 != 0 || s1 != ns) throw std::runtime_error("lobpcg: grouped update without the fused kernel");
       have_R = false;
@@ -1716,7 +1724,10 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       bk::block_mul(ch, AS, p3, p, dC, qout, AT, p3, false);
       bk::block_mul(ch, BS, p3, p, dC, qout, BT, p3, false);
     }
-    if (last) { std::swap(S, T); std::swap(AS, AT); std::swap(BS, BT); }
+    if (last) {
+      std::swap(S, T);
+      if (!lean) { std::swap(AS, AT); std::swap(BS, BT); }
+    }
     return 0;
   };
   gram_blocks(m);
@@ -1740,6 +1751,15 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   const bool conv_sinvert = P.amg && opt.eps_conv != "residual";
   conv_sinvert_now = conv_sinvert;
   fused_update = conv_sinvert && m == 32 && bk::lobpcg_update32_available() && !getenv("GENEO_LOBPCG_NO_FUSED_UPDATE");
+  static const bool no_lean = getenv("GENEO_LOBPCG_NO_LEAN") != nullptr;
+  lean = fused_update && !no_lean && !pipeline_ok && P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m);
+  if (lean) {   // the second set of product blocks is never written
+    for (double* q : {AT, BT}) {
+      owned_bufs.erase(std::find(owned_bufs.begin(), owned_bufs.end(), q));
+      bk::dfree(q);
+    }
+    AT = BT = nullptr;
+  }
   int it = 0;
   bool all_done = false;
   std::vector<int> nev_s(ns);
@@ -1828,12 +1848,16 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     // operators) cannot accumulate into the residual
     static const int refresh = getenv("GENEO_LOBPCG_REFRESH") ? atoi(getenv("GENEO_LOBPCG_REFRESH")) : 8;
     const bool refreshed = (it > 0 && refresh > 0 && it % refresh == 0);
-    if (refreshed) {
+    if (refreshed && lean) {   // the explicit Gram blocks of this iteration need A [X P] and B [X P]
+      bk::spmm_dual(*P.dual_pat, P.dual_vA, P.dual_vB, S, p3, AS, BS, p3, m);
+      bk::spmm_dual(*P.dual_pat, P.dual_vA, P.dual_vB, S + m, p3, AS + m, BS + m, p3, m);
+      info.eig_spmm += 4;
+    } else if (refreshed) {
       applyA(S, AS);
       applyB(S, BS);
     }
     // residual into the W slot, convergence test (the fused update has already uploaded the Ritz values it used)
-    if (!have_R || refreshed) bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
+    if (!have_R || (refreshed && !lean)) bk::h2d(dlam, lam.data(), sizeof(double) * (size_t)ns * m);
     double* W = S + 2 * m;
     // The device part of one iteration -- residual, preconditioner, A W, B W, the two Gram blocks: ~45 launches, many of
     // them on the small coarse levels of the V-cycle where the host cannot issue as fast as the GPU retires.  With the
@@ -1869,7 +1893,12 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     auto device_phase = [&](bool with_gram) {
       // residual block (columns locked in EARLIER iterations come out zero): already written by the fused update,
       // unless A X / B X have just been refreshed
-      if (!have_R || refreshed) bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);
+      if (lean) {
+        bk::spmm_dual_residual(*P.dual_pat, P.dual_vA, P.dual_vB, S, p3, cr, m, m, ch, dlam, dmask);
+        info.eig_spmm += 2;
+      } else if (!have_R || refreshed) {
+        bk::block_residual_norms(ch, AS, p3, BS, p3, dlam, m, cr, m, dmask, nullptr);
+      }
       precondition();
       if (P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m)) {    // A W and B W in one pass over W
         bk::spmm_dual(*P.dual_pat, P.dual_vA, P.dual_vB, W, p3, AS + 2 * m, BS + 2 * m, p3, m);
@@ -1935,7 +1964,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     if (!direct && it_graph[par] && graph_has_gram[par] == !pipe) {
       bk::graph_launch(it_graph[par]);
-      info.eig_spmm += P.amg ? 5 : 2 + opt.cheb_degree - 1;   // what device_phase counts when it runs direct
+      info.eig_spmm += (P.amg ? 5 : 2 + opt.cheb_degree - 1) + (lean ? 2 : 0);   // what device_phase counts when it runs direct
     } else {
       device_phase(!pipe);
     }

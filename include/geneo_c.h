@@ -327,6 +327,10 @@ PetscErrorCode GeneoSpmmFused(GeneoSpmv h, int epi, const double* X_dev, double*
  * not contained in pattern(A) or A not on the sliced path */
 PetscErrorCode GeneoSpmmDualTest(GeneoSpmv a, GeneoSpmv b, const double* X_dev, int ldx, double* Y1_dev, double* Y2_dev,
                                  int ldy, int m);
+/* R = mask .* (A X - B X diag(lam)) per subdomain, both products in one pass over X and neither written (the residual
+ * block of LOBPCG's lean iteration); suboff: nsub + 1 first rows, lam / mask: nsub x m HOST arrays; X_dev, R_dev device */
+PetscErrorCode GeneoSpmmDualResidualTest(GeneoSpmv a, GeneoSpmv b, const double* X_dev, int ldx, double* R_dev, int ldr,
+                                         int m, int nsub, const int* suboff, const double* lam, const double* mask);
 PetscErrorCode GeneoSpmvFusedSingle(GeneoSpmv h, int epi, const double* X_dev, double* Y_dev, const double* B_dev,
                                     double* Z_dev, const double* dinv_dev, double w);
 /* device sparse products of the multigrid set-up (test hook): op 0: C = A B, op 1: C = A^T; returns nnz(C), -1 when a
@@ -342,7 +346,8 @@ PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const dou
 
 /* fused Rayleigh-Ritz update of one LOBPCG iteration, m = 32 (test hook; host arrays): S, AS, BS n x 96 row-major
  * [X | P | W]; C nsub x 96 x 64; keep / lam / mask nsub x 32.  Out: columns 0..63 of T, AT, BT (n x 96) = [X' P'] of each
- * operand, R (n x 32) = mask .* (A X' - B X' diag(lam)). */
+ * operand, R (n x 32) = mask .* (A X' - B X' diag(lam)).  AS == NULL: the basis-only form (T from S, C, keep; the other
+ * arguments are not touched). */
 PetscErrorCode GeneoTestLobpcgUpdate(int nsub, const int* suboff, const double* S, const double* AS, const double* BS,
                                      const double* C, const double* keep, const double* lam, const double* mask,
                                      double* T, double* AT, double* BT, double* R);

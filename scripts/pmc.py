@@ -11,7 +11,7 @@ reports half the bytes of a wide streaming read, WRITE_SIZE is exact.
 `work` runs, on the bench workload's fine-level matrix (block-diagonal A_Dir of the 8 subdomains): the calibration
 kernel k_axpby on two 40 M-element vectors (reads 640 MB, writes 320 MB: also evicts the 256 MiB Infinity Cache between
 the measured launches), the CSR SpMV, the 32-column SpMM on a contiguous block (ld 32) and inside a 96-column LOBPCG
-basis (ld 96), the 96 x 96 MFMA Gram, the 96 -> 64 MFMA block update and the fused LOBPCG update; it writes the algorithmic bytes of each to
+basis (ld 96), the 96 x 96 MFMA Gram, the 96 -> 64 MFMA block update, the fused three-operand LOBPCG update and its basis-only form; it writes the algorithmic bytes of each to
 work.json (argv[-1] when it ends in .json)."""
 import csv
 import ctypes as C
@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96", "k_gram_flat": "gram96",
-           "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32": "lobpcg_update32"}
+           "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32<1>": "lobpcg_update32_basis", "k_lobpcg_update32<3>": "lobpcg_update32"}
 CALIB = 40_000_000
 
 
@@ -64,7 +64,7 @@ def work(argv):
            "spmv": a.nnz * 12 + (rows + 1) * 4 + rows * 16,
            "spmm32": a.nnz * 12 + rows * 4 + 16 * m * rows,
            "gram96": 8 * rows * (96 + 96), "blockmul96x64": 8 * rows * (96 + 64),
-           "lobpcg_update32": 8 * rows * (3 * 96 + 3 * 64 + 32)}
+           "lobpcg_update32": 8 * rows * (3 * 96 + 3 * 64 + 32), "lobpcg_update32_basis": 8 * rows * (96 + 64)}
     alg["spmm32_csr"] = alg["spmm32"]
     suboff = np.concatenate([[0], np.cumsum([len(d.l2g) for d in doms])]).astype(np.int32)
     if os.environ.get("PMC_BLOCK_KERNELS", "1") == "1":
@@ -80,6 +80,12 @@ def work(argv):
         evict()
         rc = lib.GeneoTestLobpcgUpdate(nd, suboff.ctypes.data_as(C.POINTER(C.c_int)), dp(S), dp(S), dp(S), dp(Cm), dp(vec),
                                        dp(vec), dp(vec), dp(T), dp(T), dp(T), dp(R))
+        assert rc == 0
+        # the basis-only form of the lean iteration (AS = NULL): T = [X' P'] from S
+        null = C.POINTER(C.c_double)()
+        evict()
+        rc = lib.GeneoTestLobpcgUpdate(nd, suboff.ctypes.data_as(C.POINTER(C.c_int)), dp(S), null, null, dp(Cm), dp(vec),
+                                       null, null, dp(T), null, null, null)
         assert rc == 0
     if out_json:
         json.dump(alg, open(out_json, "w"))

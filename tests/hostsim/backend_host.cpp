@@ -27,6 +27,13 @@ bool spmm_dual_available(const Csr&, int) { return false; }
 void spmm_dual(const Csr&, const double*, const double*, const double*, int, double*, double*, int, int) {
   throw std::runtime_error("spmm_dual: not in the serial backend");
 }
+void spmm_dual_residual(const Csr&, const double*, const double*, const double*, int, double*, int, int, const Chunks&,
+                        const double*, const double*) {
+  throw std::runtime_error("spmm_dual_residual: not in the serial backend");
+}
+void lobpcg_update32_basis(const Chunks&, const double*, const double*, const double*, double*) {
+  throw std::runtime_error("lobpcg_update32_basis: not in the serial backend");
+}
 int device_count() { return 0; }
 int set_device(int) { return -1; }
 int current_device() { return -1; }

@@ -442,6 +442,64 @@ def test_spmm_dual_two_operators_one_pass(lib, m):
     assert lib.GeneoSpmmDualTest(hb.h, ha.h, xd.ptr, ld, y1.ptr, y2.ptr, ld, m) == 2      # A is not inside B's pattern
 
 
+def test_lean_lobpcg_update_and_residual(lib):
+    """The two kernels of LOBPCG's lean iteration (core.cpp, `lean`): the basis-only update k_lobpcg_update32<1> -- bit-identical
+    to the S part of the three-operand kernel -- and the residual block from X alone, k_spmm_sell_dual<.., .., 1>:
+    R = mask .* (A X - B X diag(lam)) per subdomain, equal to what the separate products give (ragged subdomain boundaries
+    inside 64-row slices)."""
+    import ctypes as C
+    from geneo4petsc_amd.pc import Spmv, DeviceVector
+    rng = np.random.default_rng(21)
+    suboff = np.array([0, 1500, 1500 + 1061], dtype=np.int32)
+    n, ns = int(suboff[-1]), 2
+    S, AS, BS = (rng.random((n, 96)) - 0.5 for _ in range(3))
+    Cm = np.zeros((ns, 96, 64))
+    keep = (rng.random((ns, 32)) > 0.3).astype(np.float64)
+    Cm[:, :, :32] = rng.random((ns, 96, 32)) - 0.5
+    Cm[:, 32:, 32:] = Cm[:, 32:, :32] * keep[:, None, :]
+    lam = rng.random((ns, 32)) + 0.1
+    mask = (rng.random((ns, 32)) > 0.2).astype(np.float64)
+    T, AT, BT, T1 = (np.zeros((n, 96)) for _ in range(4))
+    R = np.zeros((n, 32))
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    arrs = [np.ascontiguousarray(a) for a in (S, AS, BS, Cm, keep, lam, mask)]
+    assert lib.GeneoTestLobpcgUpdate(ns, ip(suboff), *[p(a) for a in arrs], p(T), p(AT), p(BT), p(R)) == 0
+    null = C.POINTER(C.c_double)()
+    rc = lib.GeneoTestLobpcgUpdate(ns, ip(suboff), p(arrs[0]), null, null, p(arrs[3]), p(arrs[4]), null, null, p(T1), null, null, null)
+    assert rc == 0, lib.PCGenEOGetError(None).decode()
+    np.testing.assert_array_equal(T1[:, :64], T[:, :64])
+    # residual from X alone on a 7-point pattern with B inside A's pattern; two subdomains cut inside a slice
+    g = 24
+    e = np.ones(g)
+    t = sp.diags([e[:-1], e, e[:-1]], [-1, 0, 1])
+    i3 = sp.identity(g)
+    a = (sp.kron(sp.kron(t, i3), i3) + sp.kron(sp.kron(i3, t), i3) + sp.kron(sp.kron(i3, i3), t)).tocsr()
+    a.sort_indices()
+    a.data = rng.random(a.nnz) - 0.5
+    b = a.copy()
+    b.data = np.where(rng.random(a.nnz) < 0.8, rng.random(a.nnz) - 0.5, 0.0)
+    b.eliminate_zeros()
+    na = a.shape[0]
+    ha, hb = Spmv(a, lib), Spmv(b, lib)
+    for m in (16, 32):
+        so = np.array([0, 5001, 9000, na], dtype=np.int32)
+        lam3 = np.ascontiguousarray(rng.random((3, m)) + 0.1)
+        mask3 = np.ascontiguousarray((rng.random((3, m)) > 0.2).astype(np.float64))
+        ld = 96
+        X = rng.random((na, ld)) - 0.5
+        xd = DeviceVector.from_host(lib, X.ravel())
+        rd = DeviceVector(lib, na * m)
+        rc = lib.GeneoSpmmDualResidualTest(ha.h, hb.h, xd.ptr, ld, rd.ptr, m, m, 3, ip(so), p(lam3), p(mask3))
+        assert rc == 0, lib.PCGenEOGetError(None).decode()
+        Rd = rd.to_host().reshape(na, m)
+        ax, bx = ha.spmm(np.ascontiguousarray(X[:, :m])), hb.spmm(np.ascontiguousarray(X[:, :m]))
+        for sd in range(3):
+            rows = slice(so[sd], so[sd + 1])
+            np.testing.assert_allclose(Rd[rows], mask3[sd] * (ax[rows] - lam3[sd] * bx[rows]), rtol=0, atol=4e-16 * 8)
+            assert not Rd[rows][:, mask3[sd] == 0.0].any()
+
+
 def test_library_threads_run_on_the_librarys_device(lib):
     """The HIP current device is per host thread and a new thread starts on device 0: threads the library starts (the
     level-1 set-up on its side stream, upload helpers) must be bound to the device of the thread that configured the
