@@ -2759,6 +2759,26 @@ __global__ __launch_bounds__(256) void k_spmm_sell_dual(const int64_t* __restric
     const int64_t base = sl_ptr[s];
     const int wd = (int)((sl_ptr[s + 1] - base) >> 6);
     const int nchunk = (wd + KC - 1) / KC;
+    // RES: the subdomain of the slice's first and last row, once per slice (a per-row search would put three dependent
+    // loads in front of every store); lam / mask of that subdomain ride in registers unless the slice straddles a boundary
+    int sd0 = 0, sd1 = 0;
+    d2 lm0 = d2{0.0, 0.0}, mk0 = d2{0.0, 0.0};
+    if (RES) {
+      const int rfirst = 64 * s, rlast = (64 * s + 63 < n) ? 64 * s + 63 : n - 1;
+      int lo = 0, hi = nsub, lo1 = 0, hi1 = nsub;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (suboff[mid] <= rfirst) lo = mid; else hi = mid;
+      }
+      while (hi1 - lo1 > 1) {
+        const int mid = (lo1 + hi1) >> 1;
+        if (suboff[mid] <= rlast) lo1 = mid; else hi1 = mid;
+      }
+      sd0 = lo;
+      sd1 = lo1;
+      lm0 = *reinterpret_cast<const d2*>(lam + sd0 * (2 * LG) + 2 * q);
+      mk0 = *reinterpret_cast<const d2*>(mask + sd0 * (2 * LG) + 2 * q);
+    }
     for (int g = 0; g < NSTEP / U; ++g) {
       d2 acc1[U], acc2[U];
 #pragma unroll
@@ -2795,14 +2815,17 @@ __global__ __launch_bounds__(256) void k_spmm_sell_dual(const int64_t* __restric
         const int64_t r = (int64_t)64 * s + (g * U + u) * RS + grp;
         if (r >= n) continue;
         if (RES) {
-          int lo = 0, hi = nsub;                    // largest lo with suboff[lo] <= r
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (suboff[mid] <= r) lo = mid; else hi = mid;
+          d2 lm = lm0, mk = mk0;
+          if (sd0 != sd1) {                          // a slice across a subdomain boundary: this row's own subdomain
+            int lo = sd0, hi = sd1 + 1;              // largest lo with suboff[lo] <= r
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (suboff[mid] <= r) lo = mid; else hi = mid;
+            }
+            constexpr int mcols = 2 * LG;
+            lm = *reinterpret_cast<const d2*>(lam + lo * mcols + 2 * q);
+            mk = *reinterpret_cast<const d2*>(mask + lo * mcols + 2 * q);
           }
-          constexpr int mcols = 2 * LG;
-          const d2 lm = *reinterpret_cast<const d2*>(lam + lo * mcols + 2 * q);
-          const d2 mk = *reinterpret_cast<const d2*>(mask + lo * mcols + 2 * q);
           d2 res;
           res.x = mk.x * (acc1[u].x - lm.x * acc2[u].x);
           res.y = mk.y * (acc1[u].y - lm.y * acc2[u].y);
