@@ -154,6 +154,7 @@ SYMBOLS = {
                                   c_int_p, c_dbl_p, c_dbl_p]),
     "GeneoSpmvFusedSingle": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_double]),
+    "GeneoSetParReduceMin": (C.c_int, [C.c_int]),
     "GeneoTestLobpcgUpdate": (C.c_int, [C.c_int, c_int_p] + [c_dbl_p] * 11),
     "GeneoBlockKernel": (C.c_int, [C.c_int, C.c_int, c_int_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p,
                                    C.c_int, c_dbl_p]),

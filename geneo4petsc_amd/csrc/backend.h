@@ -191,7 +191,13 @@ struct Chunks {
   int* subptr = nullptr;   // nsub+1 : first chunk of each subdomain
   int* suboff = nullptr;   // nsub+1 : first row of each subdomain
   double* partial = nullptr;  // 4*nchunk scratch
+  double* totals = nullptr;   // 4*nsub: per-subdomain totals of the partial slots (large subdomains: reduced once per launch)
+  int maxsub_chunks = 0;      // chunks of the largest subdomain
 };
+// per-subdomain reductions of chunk partials switch to their cooperative forms above this many chunks per subdomain
+// (default 1024, GENEO_PAR_REDUCE_MIN; changing it while a HIP graph of the solver exists is not supported)
+void set_par_reduce_min(int chunks);
+int get_par_reduce_min();
 Chunks chunks_upload(int nsub, const int* h_suboff /*nsub+1: absolute first rows, h_suboff[0] need not be 0*/);
 void   chunks_free(Chunks& c);
 // out[s*stride + slot] = sum over subdomain s of x.*y

@@ -3187,9 +3187,11 @@ Chunks chunks_upload(int nsub, const int* h_suboff) {
       ln.push_back(std::min(CHUNK, h_suboff[s + 1] - a));
       sb.push_back(s);
     }
+    c.maxsub_chunks = std::max(c.maxsub_chunks, (int)st.size() - sp.back());
     sp.push_back((int)st.size());
   }
   c.nchunk = (int)st.size();
+  c.totals = (double*)alloc(sizeof(double) * 4 * (size_t)std::max(1, nsub));
   c.start = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
   c.len = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
   c.sub = (int*)alloc(sizeof(int) * std::max<size_t>(1, st.size()));
@@ -3206,7 +3208,7 @@ Chunks chunks_upload(int nsub, const int* h_suboff) {
 void gram_plan_drop(const Chunks& c);
 void chunks_free(Chunks& c) {
   if (c.start) gram_plan_drop(c);
-  dfree(c.start); dfree(c.len); dfree(c.sub); dfree(c.subptr); dfree(c.partial); dfree(c.suboff);
+  dfree(c.start); dfree(c.len); dfree(c.sub); dfree(c.subptr); dfree(c.partial); dfree(c.suboff); dfree(c.totals);
   c = Chunks();
 }
 
@@ -3226,6 +3228,27 @@ __device__ __forceinline__ double sub_total_block(const double* __restrict__ par
   return block_sum_256(s, sm);
 }
 
+// Large subdomains (the one-subdomain-per-GPU layout: 6 400 chunks): every per-subdomain reduction of chunk partials is
+// done cooperatively -- one workgroup per subdomain (and slot) instead of one THREAD per subdomain, and once per launch
+// instead of once per chunk workgroup.  Lists of at most g_par_reduce_min chunks keep the forms (and the summation
+// order, hence the bits) they have had since round 1.  GENEO_PAR_REDUCE_MIN overrides the threshold (tests: 0).
+static int g_par_reduce_min = getenv("GENEO_PAR_REDUCE_MIN") ? atoi(getenv("GENEO_PAR_REDUCE_MIN")) : 1024;
+static inline bool big_subs(const Chunks& c) { return c.maxsub_chunks > g_par_reduce_min; }
+void set_par_reduce_min(int chunks) { g_par_reduce_min = chunks; }
+int get_par_reduce_min() { return g_par_reduce_min; }
+// totals[s * 4 + slot] = sub_total_block(slot) for the slots of `mask` (bit k: slot k); grid (nsub, 4)
+__global__ __launch_bounds__(256) void k_sub_totals(const int* __restrict__ subptr, const double* __restrict__ part,
+                                                    int nchunk, int mask, double* __restrict__ totals) {
+  __shared__ double sm[4];
+  const int s = blockIdx.x, slot = blockIdx.y;
+  if (!((mask >> slot) & 1)) return;
+  const double t = sub_total_block(part, nchunk, slot, subptr[s], subptr[s + 1], sm);
+  if (threadIdx.x == 0) totals[(int64_t)s * 4 + slot] = t;
+}
+static void sub_totals(const Chunks& c, int mask) {
+  hipLaunchKernelGGL(k_sub_totals, dim3(c.nsub, 4), dim3(256), 0, g_stream, c.subptr, c.partial, c.nchunk, mask, c.totals);
+}
+
 __global__ __launch_bounds__(256) void k_seg_dot1(const int* __restrict__ start, const int* __restrict__ len,
                                                   const double* __restrict__ x, const double* __restrict__ y,
                                                   double* __restrict__ part, int nchunk, int slot) {
@@ -3243,10 +3266,22 @@ __global__ void k_seg_dot2(const int* __restrict__ subptr, const double* __restr
   if (s >= nsub) return;
   out[(int64_t)s * stride + slot] = sub_total(part, nchunk, pslot, subptr[s], subptr[s + 1]);
 }
+__global__ __launch_bounds__(256) void k_seg_dot2_big(const int* __restrict__ subptr, const double* __restrict__ part,
+                                                      int nchunk, int pslot, double* __restrict__ out, int stride, int slot) {
+  __shared__ double sm[4];
+  const int s = blockIdx.x;
+  const double t = sub_total_block(part, nchunk, pslot, subptr[s], subptr[s + 1], sm);
+  if (threadIdx.x == 0) out[(int64_t)s * stride + slot] = t;
+}
 void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot) {
   if (c.nchunk == 0) return;
   hipLaunchKernelGGL(k_seg_dot1, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, x, y, c.partial,
                      c.nchunk, 3);
+  if (big_subs(c)) {
+    hipLaunchKernelGGL(k_seg_dot2_big, dim3(c.nsub), dim3(256), 0, g_stream, c.subptr, c.partial, c.nchunk, 3, out, stride,
+                       slot);
+    return;
+  }
   hipLaunchKernelGGL(k_seg_dot2, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk,
                      3, out, stride, slot, c.nsub);
 }
@@ -3282,11 +3317,11 @@ __global__ __launch_bounds__(256) void k_cg_start(const int* __restrict__ start,
   }
 }
 __global__ void k_cg_start2(const int* __restrict__ subptr, const double* __restrict__ part, int nchunk,
-                            double* __restrict__ sc, int nsub) {
+                            double* __restrict__ sc, int nsub, const double* __restrict__ totals) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsub) return;
-  const double rz = sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
-  const double rr = sub_total(part, nchunk, 2, subptr[s], subptr[s + 1]);
+  const double rz = totals ? totals[(int64_t)s * 4 + 1] : sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
+  const double rr = totals ? totals[(int64_t)s * 4 + 2] : sub_total(part, nchunk, 2, subptr[s], subptr[s + 1]);
   double* q = sc + (int64_t)s * 8;
   q[0] = rz; q[1] = rz; q[2] = 0.0; q[3] = rr; q[4] = 0.0; q[5] = 0.0;
   q[6] = (rr > 0.0) ? 1.0 : 0.0;
@@ -3297,8 +3332,10 @@ void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, doub
   if (c.nchunk == 0) return;
   hipLaunchKernelGGL(k_cg_start, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, x, r, z, p, b, dinv,
                      c.partial, c.nchunk);
+  const bool big = big_subs(c);
+  if (big) sub_totals(c, 6);
   hipLaunchKernelGGL(k_cg_start2, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk,
-                     sc, c.nsub);
+                     sc, c.nsub, big ? c.totals : (const double*)nullptr);
 }
 void seg_partial(const Chunks& c, const double* x, const double* y, int slot) {
   if (c.nchunk == 0) return;
@@ -3307,17 +3344,19 @@ void seg_partial(const Chunks& c, const double* x, const double* y, int slot) {
 }
 // second half of cg_start when the caller preconditions itself: p = z, rz slots from partial slot 1
 __global__ void k_cg_start3(const int* __restrict__ subptr, const double* __restrict__ part, int nchunk,
-                            double* __restrict__ sc, int nsub) {
+                            double* __restrict__ sc, int nsub, const double* __restrict__ totals) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsub) return;
-  const double rz = sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
+  const double rz = totals ? totals[(int64_t)s * 4 + 1] : sub_total(part, nchunk, 1, subptr[s], subptr[s + 1]);
   sc[(int64_t)s * 8 + 0] = rz;
   sc[(int64_t)s * 8 + 1] = rz;
 }
 void cg_set_rz(const Chunks& c, double* sc) {
   if (c.nchunk == 0) return;
+  const bool big = big_subs(c);
+  if (big) sub_totals(c, 2);
   hipLaunchKernelGGL(k_cg_start3, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, c.subptr, c.partial, c.nchunk, sc,
-                     c.nsub);
+                     c.nsub, big ? c.totals : (const double*)nullptr);
 }
 void seg_pap(const Chunks& c, const double* p, const double* q) {
   if (c.nchunk == 0) return;
@@ -3330,12 +3369,13 @@ __global__ __launch_bounds__(256) void k_cg_update(const int* __restrict__ start
                                                    double* __restrict__ r, double* __restrict__ z,
                                                    const double* __restrict__ p, const double* __restrict__ q,
                                                    const double* __restrict__ dinv, double* __restrict__ part,
-                                                   int nchunk) {
+                                                   int nchunk, const double* __restrict__ totals) {
   __shared__ double sm[4];
   const int c = blockIdx.x;
   const int s = sub[c];
   const int c0 = subptr[s], c1 = subptr[s + 1];
-  const double pap = sub_total_block(part, nchunk, 0, c0, c1, sm);
+  // (totals: the same sum, computed once per launch by k_sub_totals -- bit-identical)
+  const double pap = totals ? totals[(int64_t)s * 4 + 0] : sub_total_block(part, nchunk, 0, c0, c1, sm);
   const double rz = sc[(int64_t)s * 8 + parity];
   const double active = sc[(int64_t)s * 8 + 6];
   const double alpha = (active != 0.0 && pap != 0.0) ? rz / pap : 0.0;
@@ -3367,20 +3407,23 @@ __global__ __launch_bounds__(256) void k_cg_update(const int* __restrict__ start
 void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, double* z, const double* p,
                  const double* q, const double* dinv) {
   if (c.nchunk == 0) return;
+  const bool big = big_subs(c);
+  if (big) sub_totals(c, 1);
   hipLaunchKernelGGL(k_cg_update, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.subptr, sc,
-                     parity, x, r, z, p, q, dinv, c.partial, c.nchunk);
+                     parity, x, r, z, p, q, dinv, c.partial, c.nchunk, big ? c.totals : (const double*)nullptr);
 }
 __global__ __launch_bounds__(256) void k_cg_direction(const int* __restrict__ start, const int* __restrict__ len,
                                                       const int* __restrict__ sub, const int* __restrict__ subptr,
                                                       double* __restrict__ sc, int parity, double* __restrict__ p,
                                                       const double* __restrict__ z, double tol2,
-                                                      const double* __restrict__ part, int nchunk) {
+                                                      const double* __restrict__ part, int nchunk,
+                                                      const double* __restrict__ totals) {
   __shared__ double sm[4];
   const int c = blockIdx.x;
   const int s = sub[c];
   const int c0 = subptr[s], c1 = subptr[s + 1];
-  const double nrz = sub_total_block(part, nchunk, 1, c0, c1, sm);
-  const double nrr = sub_total_block(part, nchunk, 2, c0, c1, sm);
+  const double nrz = totals ? totals[(int64_t)s * 4 + 1] : sub_total_block(part, nchunk, 1, c0, c1, sm);
+  const double nrr = totals ? totals[(int64_t)s * 4 + 2] : sub_total_block(part, nchunk, 2, c0, c1, sm);
   const double rz = sc[(int64_t)s * 8 + parity];
   const double was_active = sc[(int64_t)s * 8 + 6];
   const double rr0 = sc[(int64_t)s * 8 + 7];
@@ -3407,8 +3450,10 @@ __global__ void k_cg_flag(double* __restrict__ sc, double tol2, int nsub) {
 }
 void cg_direction(const Chunks& c, double* sc, int parity, double* p, const double* z, double tol2) {
   if (c.nchunk == 0) return;
+  const bool big = big_subs(c);
+  if (big) sub_totals(c, 6);
   hipLaunchKernelGGL(k_cg_direction, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.subptr, sc,
-                     parity, p, z, tol2, c.partial, c.nchunk);
+                     parity, p, z, tol2, c.partial, c.nchunk, big ? c.totals : (const double*)nullptr);
   hipLaunchKernelGGL(k_cg_flag, dim3(grid1d(c.nsub, 64)), dim3(64), 0, g_stream, sc, tol2, c.nsub);
 }
 
@@ -3700,12 +3745,39 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const int* __restrict__ gsu
 }
 
 // host-side cache of the gram grouping for a Chunks object (keyed by its device pointer)
+// Large subdomains (thousands of partial matrices each): two stages -- GZ workgroups per 64 entries, workgroup z sums the
+// partial matrices first + 4 z + k, + 4 GZ, ... (k = thread set) and combines its four sets in order; the second stage adds
+// the GZ results in order.  6 383 partial 64 x 96 Grams of ONE subdomain: 0.75 ms -> the time of reading them once.
+__global__ __launch_bounds__(256) void k_gram_reduce_z(const int* __restrict__ gsubptr, const double* __restrict__ Gpart,
+                                                       int pq, int GZ, double* __restrict__ out) {
+  __shared__ double sm[4][64];
+  const int s = blockIdx.y, z = blockIdx.z;
+  const int el = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  double acc = 0.0;
+  if (e < pq)
+    for (int g = gsubptr[s] + 4 * z + k; g < gsubptr[s + 1]; g += 4 * GZ) acc += Gpart[(int64_t)g * pq + e];
+  sm[k][el] = acc;
+  __syncthreads();
+  if (k == 0 && e < pq) out[((int64_t)s * GZ + z) * pq + e] = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+}
+__global__ __launch_bounds__(256) void k_gram_reduce_fin(const double* __restrict__ part2, int pq, int GZ,
+                                                         double* __restrict__ G) {
+  const int s = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= pq) return;
+  double acc = 0.0;
+  for (int z = 0; z < GZ; ++z) acc += part2[((int64_t)s * GZ + z) * pq + e];
+  G[(int64_t)s * pq + e] = acc;
+}
 struct GramPlan {
   const int* key = nullptr;
   int ngroup = 0, nsub = 0;
   int *gfirst = nullptr, *gcount = nullptr, *gsubptr = nullptr;
   double* part = nullptr;
   size_t part_doubles = 0;
+  double* part2 = nullptr;      // stage-1 results of the two-stage reduction (large subdomains)
+  size_t part2_doubles = 0;
 };
 static std::vector<GramPlan> g_plans;
 static GramPlan& gram_plan(const Chunks& c) {
@@ -3739,6 +3811,7 @@ void gram_plan_drop(const Chunks& c) {
   for (size_t i = 0; i < g_plans.size(); ++i)
     if (g_plans[i].key == c.start) {
       dfree(g_plans[i].gfirst); dfree(g_plans[i].gcount); dfree(g_plans[i].gsubptr); dfree(g_plans[i].part);
+      dfree(g_plans[i].part2);
       g_plans.erase(g_plans.begin() + i);
       return;
     }
@@ -3799,6 +3872,19 @@ static void gram_impl(const Chunks& c, const double* S, int lds_, int p, const d
     const size_t sm = sizeof(double) * 16 * (size_t)(p + q);
     hipLaunchKernelGGL(k_gram_fma, dim3(pl.ngroup), dim3(256), sm, g_stream, c.start, c.len, pl.gfirst, pl.gcount,
                        S, lds_, p, T, ldt_, q, pl.part, S2 ? S2 : S, lds2_, psplit);
+  }
+  if (big_subs(c)) {
+    constexpr int GZ = 16;
+    const size_t need2 = (size_t)c.nsub * GZ * p * q;
+    if (pl.part2_doubles < need2) {
+      dfree(pl.part2);
+      pl.part2 = (double*)alloc(sizeof(double) * need2);
+      pl.part2_doubles = need2;
+    }
+    hipLaunchKernelGGL(k_gram_reduce_z, dim3(grid1d(p * q, 64), c.nsub, GZ), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
+                       p * q, GZ, pl.part2);
+    hipLaunchKernelGGL(k_gram_reduce_fin, dim3(grid1d(p * q, 256), c.nsub), dim3(256), 0, g_stream, pl.part2, p * q, GZ, G);
+    return;
   }
   hipLaunchKernelGGL(k_gram_reduce, dim3(grid1d(p * q, 64), c.nsub), dim3(256), 0, g_stream, pl.gsubptr, pl.part,
                      p * q, G);
@@ -4433,6 +4519,18 @@ __global__ void k_zt_reduce(const int* __restrict__ subptr, const int* __restric
   for (int c = subptr[s]; c < subptr[s + 1]; ++c) t += part[(int64_t)c * kmax + j];
   yE[zoff[s] + j] = t;
 }
+// large subdomains: one workgroup per (subdomain, column), strided partial sums + the fixed-order block reduction
+__global__ __launch_bounds__(256) void k_zt_reduce_big(const int* __restrict__ subptr, const int* __restrict__ ksub,
+                                                       const int* __restrict__ zoff, const double* __restrict__ part, int kmax,
+                                                       double* __restrict__ yE) {
+  __shared__ double sm[4];
+  const int s = blockIdx.x, j = blockIdx.y;
+  if (j >= ksub[s]) return;
+  double t = 0.0;
+  for (int c = subptr[s] + (int)threadIdx.x; c < subptr[s + 1]; c += 256) t += part[(int64_t)c * kmax + j];
+  t = block_sum_256(t, sm);
+  if (threadIdx.x == 0) yE[zoff[s] + j] = t;
+}
 void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff, int kmax,
               const double* xL, double* yE, int dimE_total) {
   if (kmax > ZMAXK) throw std::runtime_error("zt_apply: more than 256 coarse vectors in one subdomain");
@@ -4441,8 +4539,11 @@ void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int*
   double* part = colpart((size_t)c.nchunk * kmax);
   hipLaunchKernelGGL(k_zt_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, Z, zbase,
                      ksub, xL, part, kmax);
-  hipLaunchKernelGGL(k_zt_reduce, dim3(c.nsub), dim3(((kmax + 63) / 64) * 64), 0, g_stream, c.subptr, ksub, zoff,
-                     part, kmax, yE);
+  if (big_subs(c))
+    hipLaunchKernelGGL(k_zt_reduce_big, dim3(c.nsub, kmax), dim3(256), 0, g_stream, c.subptr, ksub, zoff, part, kmax, yE);
+  else
+    hipLaunchKernelGGL(k_zt_reduce, dim3(c.nsub), dim3(((kmax + 63) / 64) * 64), 0, g_stream, c.subptr, ksub, zoff,
+                       part, kmax, yE);
 }
 __global__ __launch_bounds__(256) void k_z_apply(const int* __restrict__ cstart, const int* __restrict__ clen,
                                                  const int* __restrict__ csub, const int* __restrict__ suboff,

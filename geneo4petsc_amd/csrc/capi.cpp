@@ -687,6 +687,13 @@ long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, i
   }
 }
 
+// threshold (chunks per subdomain) above which the per-subdomain reductions take their cooperative forms; returns the
+// previous value.  Set it BEFORE creating the PC whose solves it should govern (captured HIP graphs keep their launches).
+int GeneoSetParReduceMin(int chunks) {
+  const int old = bk::get_par_reduce_min();
+  bk::set_par_reduce_min(chunks);
+  return old;
+}
 // test hook of the fused LOBPCG update (m = 32): host arrays in, host arrays out
 PetscErrorCode GeneoTestLobpcgUpdate(int nsub, const int* suboff, const double* S, const double* AS, const double* BS,
                                      const double* C, const double* keep, const double* lam, const double* mask,

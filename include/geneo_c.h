@@ -344,6 +344,11 @@ long long GeneoTestSparseProduct(int op, const GeneoCsr* A, const GeneoCsr* B, i
 PetscErrorCode GeneoBlockKernel(int kind, int nsub, const int* suboff, const double* S, int p, const double* T_or_C,
                                 int q, double* out, int reps, double* ms_avg);
 
+/* Per-subdomain reductions (dot products of the batched PCG, Z^T x, Gram partials) switch to their cooperative forms --
+ * one workgroup per subdomain, once per launch -- above this many 1024-row chunks per subdomain (default 1024, also
+ * GENEO_PAR_REDUCE_MIN): the one-subdomain-per-GPU layout of the benchmark's configuration.  Returns the previous value;
+ * set it before creating the PC it should govern. */
+int GeneoSetParReduceMin(int chunks);
 /* fused Rayleigh-Ritz update of one LOBPCG iteration, m = 32 (test hook; host arrays): S, AS, BS n x 96 row-major
  * [X | P | W]; C nsub x 96 x 64; keep / lam / mask nsub x 32.  Out: columns 0..63 of T, AT, BT (n x 96) = [X' P'] of each
  * operand, R (n x 32) = mask .* (A X' - B X' diag(lam)).  AS == NULL: the basis-only form (T from S, C, keep; the other

@@ -34,6 +34,8 @@ void spmm_dual_residual(const Csr&, const double*, const double*, const double*,
 void lobpcg_update32_basis(const Chunks&, const double*, const double*, const double*, double*) {
   throw std::runtime_error("lobpcg_update32_basis: not in the serial backend");
 }
+void set_par_reduce_min(int) {}
+int get_par_reduce_min() { return 0; }
 int device_count() { return 0; }
 int set_device(int) { return -1; }
 int current_device() { return -1; }

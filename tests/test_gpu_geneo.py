@@ -267,3 +267,21 @@ def test_singular_neumann_matrices_get_null_pivot_fixing(lib):
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "gmres", "-amg_coarse_size", "100"] + TIGHT
     info = cases.check_singular_neumann_case(lib, 20, argv)
     assert info["amg_levels"] >= 3
+
+
+@pytest.mark.parametrize("lvl,ksp,overlap", [("SRAS,1", "cg", 2), ("RAS,1", "gmres", 1), ("ASM,H1", "cg", 1)])
+def test_cooperative_reductions_of_large_subdomains(lib, lvl, ksp, overlap):
+    """The one-subdomain-per-GPU layout of the benchmark's configuration has thousands of 1024-row chunks per subdomain:
+    above GENEO_PAR_REDUCE_MIN chunks the per-subdomain reductions (the batched PCG's scalars, Z^T x, the Gram partials)
+    run cooperatively -- one workgroup per subdomain, once per launch (k_sub_totals, k_zt_reduce_big, k_gram_reduce_z).
+    Forced here on small cases (threshold 0): full parity with the oracle, and the same counts as the default forms."""
+    argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp] + TIGHT
+    n, parts = 12, (2, 2, 2)          # the cases of test_modes_match_oracle
+    its_default, info_default = cases.compare_with_oracle(lib, n, parts, overlap, argv)
+    old = lib.GeneoSetParReduceMin(0)
+    try:
+        assert lib.GeneoSetParReduceMin(0) == 0
+        its, info = cases.compare_with_oracle(lib, n, parts, overlap, argv)
+    finally:
+        lib.GeneoSetParReduceMin(old)
+    assert its == its_default and info["dimE"] == info_default["dimE"]
