@@ -2374,6 +2374,25 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ row
         }
         const int cnt = (b - base < LPR) ? b - base : LPR;
         int k = 0;
+        // eight X rows in flight for the long rows of the restriction operators (100 entries per row, a few thousand
+        // rows: the launch is one latency chain per row); the products are added in the order of the two-at-a-time
+        // loop below, so the sums are bit-identical to it
+        for (; k + 7 < cnt; k += 8) {
+          double xv[8], vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int cu = __shfl(myc, k + u, LPR);
+            vv[u] = __shfl(myv, k + u, LPR);
+            xv[u] = (j < m) ? X[(int64_t)cu * ldx + j] : 0.0;
+          }
+          if (j < m) {
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+              s0 += vv[u] * xv[u];
+              s1 += vv[u + 1] * xv[u + 1];
+            }
+          }
+        }
         for (; k + 1 < cnt; k += 2) {
           const int c0 = __shfl(myc, k, LPR), c1 = __shfl(myc, k + 1, LPR);
           const double v0 = __shfl(myv, k, LPR), v1 = __shfl(myv, k + 1, LPR);
