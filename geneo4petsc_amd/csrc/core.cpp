@@ -1753,6 +1753,9 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   fused_update = conv_sinvert && m == 32 && bk::lobpcg_update32_available() && !getenv("GENEO_LOBPCG_NO_FUSED_UPDATE");
   static const bool no_lean = getenv("GENEO_LOBPCG_NO_LEAN") != nullptr;
   lean = fused_update && !no_lean && !pipeline_ok && P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m);
+  if (getenv("GENEO_DEBUG") && !lean)
+    fprintf(stderr, "[lobpcg %s] carried form: shift-invert test %d, block %d, fused update %d, shared pattern %d\n", P.label,
+            (int)conv_sinvert, m, (int)fused_update, (int)(P.dual_pat != nullptr));
   if (lean) {   // the second set of product blocks is never written
     for (double* q : {AT, BT}) {
       owned_bufs.erase(std::find(owned_bufs.begin(), owned_bufs.end(), q));
@@ -2036,8 +2039,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
   bk::sync();
   if (getenv("GENEO_DEBUG"))
-    fprintf(stderr, "[lobpcg %s] %d iterations %.3f s: host Rayleigh-Ritz %.3f s (+ %.3f s of Gram propagation behind the device phase), waiting for the Gram blocks %.3f s\n", P.label, it,
-            secs(t_lob0, clk::now()), t_rr_host, t_prop_host, t_dev_wait);
+    fprintf(stderr, "[lobpcg %s] %d iterations (%s) %.3f s: host Rayleigh-Ritz %.3f s (+ %.3f s of Gram propagation behind the device phase), waiting for the Gram blocks %.3f s\n", P.label, it,
+            lean ? "lean: S alone carried" : "A S, B S carried", secs(t_lob0, clk::now()), t_rr_host, t_prop_host, t_dev_wait);
   cleanup();
   if (!all_done) {
     // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).

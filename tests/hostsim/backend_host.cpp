@@ -22,17 +22,68 @@ const char* name() { return "hostsim"; }
 void set_stream(void* s) { g_stream = s; }
 void* get_stream() { return g_stream; }
 void sync() {}
-double* sell_values_on(const Csr&, const Csr&) { return nullptr; }   // the serial backend has no shared-pattern product
-bool spmm_dual_available(const Csr&, int) { return false; }
-void spmm_dual(const Csr&, const double*, const double*, const double*, int, double*, double*, int, int) {
-  throw std::runtime_error("spmm_dual: not in the serial backend");
+// Two operators on one pattern (LOBPCG's A W / B W pass and the residual product of its lean iteration): here the shared
+// pattern is a's CSR pattern and the value arrays are indexed like a.val (csr_scaled_alias sets sl_val = val).
+double* sell_values_on(const Csr& a, const Csr& b) {
+  if (a.n != b.n) return nullptr;
+  double* out = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
+  for (int r = 0; r < a.n; ++r) {
+    int found = 0;
+    for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) {
+      out[k] = 0.0;
+      for (int q = b.rowptr[r]; q < b.rowptr[r + 1]; ++q)
+        if (b.col[q] == a.col[k]) { out[k] = b.val[q]; ++found; break; }
+    }
+    if (found != b.rowptr[r + 1] - b.rowptr[r]) { dfree(out); return nullptr; }   // pattern(b) not inside pattern(a)
+  }
+  return out;
 }
-void spmm_dual_residual(const Csr&, const double*, const double*, const double*, int, double*, int, int, const Chunks&,
-                        const double*, const double*) {
-  throw std::runtime_error("spmm_dual_residual: not in the serial backend");
+bool spmm_dual_available(const Csr& a, int m) { return a.n > 0 && (m == 16 || m == 32 || m == 64); }
+void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* Y1, double* Y2, int ldy,
+               int m) {
+  for (int r = 0; r < a.n; ++r)
+    for (int j = 0; j < m; ++j) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) {
+        const double x = X[(int64_t)a.col[k] * ldx + j];
+        s1 += v1[k] * x;
+        s2 += v2[k] * x;
+      }
+      Y1[(int64_t)r * ldy + j] = s1;
+      Y2[(int64_t)r * ldy + j] = s2;
+    }
 }
-void lobpcg_update32_basis(const Chunks&, const double*, const double*, const double*, double*) {
-  throw std::runtime_error("lobpcg_update32_basis: not in the serial backend");
+void spmm_dual_residual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* R, int ldr, int m,
+                        const Chunks& c, const double* lam, const double* mask) {
+  for (int s = 0; s < c.nsub; ++s)
+    for (int r = c.suboff[s]; r < c.suboff[s + 1]; ++r)
+      for (int j = 0; j < m; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) {
+          const double x = X[(int64_t)a.col[k] * ldx + j];
+          s1 += v1[k] * x;
+          s2 += v2[k] * x;
+        }
+        R[(int64_t)r * ldr + j] = mask[s * m + j] * (s1 - lam[s * m + j] * s2);
+      }
+}
+void lobpcg_update32_basis(const Chunks& c, const double* S, const double* C, const double* keep, double* T) {
+  std::vector<double> pw(32);
+  for (int s = 0; s < c.nsub; ++s)
+    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      const double* row = S + (int64_t)i * 96;
+      const double* Cs = C + (int64_t)s * 96 * 64;
+      double* out = T + (int64_t)i * 96;
+      for (int j = 0; j < 32; ++j) {
+        double w = 0.0;
+        for (int k = 32; k < 96; ++k) w += row[k] * Cs[(int64_t)k * 64 + j];
+        double x = w;
+        for (int k = 0; k < 32; ++k) x += row[k] * Cs[(int64_t)k * 64 + j];
+        pw[j] = keep[s * 32 + j] * w;
+        out[j] = x;
+      }
+      for (int j = 0; j < 32; ++j) out[32 + j] = pw[j];
+    }
 }
 void set_par_reduce_min(int) {}
 int get_par_reduce_min() { return 0; }
@@ -134,6 +185,7 @@ Csr csr_scaled_alias(const Csr& a, const double* rs, const double* cs, bool col_
   b.val = (double*)alloc(sizeof(double) * std::max<size_t>(1, (size_t)a.nnz));
   for (int r = 0; r < a.n; ++r)
     for (int k = a.rowptr[r]; k < a.rowptr[r + 1]; ++k) b.val[k] = (rs ? rs[r] : 1.0) * a.val[k] * (cs ? cs[a.col[k]] : 1.0);
+  b.sl_val = b.val;      // "values on the owner's pattern" of the two-operator products (never freed on its own)
   return b;
 }
 bool post_matrix(Csr& ap, const Csr& p, const double* dinv, double w) {
