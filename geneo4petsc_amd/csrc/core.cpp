@@ -1752,7 +1752,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   conv_sinvert_now = conv_sinvert;
   fused_update = conv_sinvert && m == 32 && bk::lobpcg_update32_available() && !getenv("GENEO_LOBPCG_NO_FUSED_UPDATE");
   static const bool no_lean = getenv("GENEO_LOBPCG_NO_LEAN") != nullptr;
-  lean = fused_update && !no_lean && !pipeline_ok && P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m);
+  // (not with GENEO_LOBPCG_FULL_GRAM: explicit 96 x 96 Grams in every iteration read all of A S and B S)
+  lean = fused_update && !no_lean && !pipeline_ok && !full_gram && P.dual_pat && bk::spmm_dual_available(*P.dual_pat, m);
   if (getenv("GENEO_DEBUG") && !lean)
     fprintf(stderr, "[lobpcg %s] carried form: shift-invert test %d, block %d, fused update %d, shared pattern %d\n", P.label,
             (int)conv_sinvert, m, (int)fused_update, (int)(P.dual_pat != nullptr));
