@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -203,9 +204,29 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
     return v * v >= t2 * dg[i - r0] * dg[j - r0];
   };
   // strong neighbour lists (diagonal included when it passes the test, as the loops below always treated it), per range
+  // (scnt, join: every entry that is read has been written by the passes below -- no serial fill of 26 MB arrays, which
+  // together with the serial tail loops were 0.05 of the 0.08 s a 6.5 M-row block took, 0.047 s of it on the critical path
+  // of one rank of 368^3: the seeding pass itself is 0.015 s)
+  // theta = 0 (mesh matrices, LOBPCG's hierarchy): every non-zero entry is strong -- the seeding pass reads the matrix
+  // itself, and only the rows of nodes that are still free (no list to build: one pass over 45 M entries less)
+  // (the serial pass is the critical resource: it should not read the values -- they only matter when the block stores
+  // explicit zeros, which a parallel scan rules out first; with zeros stored the lists are built as for theta > 0)
+  bool direct = (theta <= 0.0);
+  if (direct) {
+    std::vector<char> zero_in(nthreads, 0);
+    ranges([&](int t, int b, int e) {
+      const double* v = a.val.data();
+      char z = 0;
+      for (int64_t k = a.rowptr[b]; k < a.rowptr[e]; ++k) z |= (v[k] == 0.0);
+      zero_in[t] = z;
+    });
+    for (int t = 0; t < nthreads; ++t)
+      if (zero_in[t]) direct = false;
+  }
   std::vector<std::vector<int>> scol(nthreads);
-  std::vector<int> scnt(nb, 0);
-  ranges([&](int t, int b, int e) {
+  std::unique_ptr<int[]> scnt_own(new int[direct ? 1 : nb]);
+  int* scnt = scnt_own.get();
+  if (!direct) ranges([&](int t, int b, int e) {
     std::vector<int>& out = scol[t];
     out.reserve((size_t)(a.rowptr[e] - a.rowptr[b]) / (theta > 0.0 ? 3 : 1) + 16);
     for (int i = b; i < e; ++i) {
@@ -215,6 +236,22 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
       scnt[i - r0] = c;
     }
   });
+  const auto t_ph1 = std::chrono::high_resolution_clock::now();
+  if (direct) {                           // phase 1 on the matrix rows: same visiting order, same predicate
+    for (int i = r0; i < r1; ++i) {
+      if (agg[i] >= 0) continue;
+      const int ka = a.rowptr[i], kb = a.rowptr[i + 1];
+      bool ok = true;
+      for (int k = ka; k < kb; ++k) {
+        const int j = a.col[k];
+        if (j != i && agg[j] >= 0) { ok = false; break; }
+      }
+      if (ok) {
+        for (int k = ka; k < kb; ++k) agg[a.col[k]] = na;
+        agg[i] = na++;
+      }
+    }
+  } else
   for (int t = 0; t < nthreads; ++t) {   // phase 1: a free node whose whole (strong) neighbourhood is free seeds an aggregate
     const int b = (t == 0) ? r0 : r0 + (int)((int64_t)nb * t / nthreads);
     const int e = (nthreads == 1) ? r1 : r0 + (int)((int64_t)nb * (t + 1) / nthreads);
@@ -235,9 +272,15 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
       sp += c;
     }
   }
-  std::vector<int> join(nb, -1);
-  ranges([&](int, int b, int e) {        // phase 2: leftovers join the most strongly connected aggregate (of phase 1)
+  if (getenv("GENEO_DEBUG") && nb > 500000)
+    fprintf(stderr, "[amg/host] aggregation of a %d-row block on %d thread(s): serial seeding pass %.3f s\n", nb, nthreads,
+            std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t_ph1).count());
+  std::unique_ptr<int[]> join_own(new int[nb]);
+  int* join = join_own.get();
+  std::vector<int64_t> left(nthreads, 0);       // nodes without an aggregate after phase 2, per range
+  ranges([&](int t, int b, int e) {      // phase 2: leftovers join the most strongly connected aggregate (of phase 1)
     for (int i = b; i < e; ++i) {
+      join[i - r0] = -1;
       if (agg[i] >= 0) continue;
       double best = 0.0;
       for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
@@ -249,10 +292,21 @@ static int aggregate_block(const HostCsr& a, int r0, int r1, std::vector<int>& a
       }
     }
   });
-  for (int i = r0; i < r1; ++i)
-    if (agg[i] < 0 && join[i - r0] >= 0) agg[i] = join[i - r0];
-  for (int i = r0; i < r1; ++i)  // phase 3: isolated nodes
-    if (agg[i] < 0) agg[i] = na++;
+  // (phase 2 reads the aggregates of phase 1 only: the assignments wait until every range is through)
+  ranges([&](int t, int b, int e) {
+    int64_t l = 0;
+    for (int i = b; i < e; ++i)
+      if (agg[i] < 0) {
+        if (join[i - r0] >= 0) agg[i] = join[i - r0];
+        else ++l;
+      }
+    left[t] = l;
+  });
+  int64_t nleft = 0;
+  for (int t = 0; t < nthreads; ++t) nleft += left[t];
+  if (nleft)
+    for (int i = r0; i < r1; ++i)  // phase 3: isolated nodes, numbered in row order
+      if (agg[i] < 0) agg[i] = na++;
   return na;
 }
 // host threads one block's aggregation may use when `nblocks` of them run side by side
@@ -596,7 +650,9 @@ void AmgDevice::alloc_level_buffers(Lvl& L, bool coarse) {
 AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& so, const AmgParams& prm, int l) {
   AmgLevelHostPart h;
   const int nsub = (int)so.size() - 1;
+  const auto t_hp0 = std::chrono::high_resolution_clock::now();
   h.rho = gershgorin_rho(Ah, h.dinv);
+  const auto t_hp1 = std::chrono::high_resolution_clock::now();
   int maxblk = 0;
   for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, so[s + 1] - so[s]);
   h.last = (maxblk <= prm.coarse_size || l + 1 >= prm.max_levels);
@@ -610,11 +666,19 @@ AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& 
       th.emplace_back([&, s]() { nagg[s] = aggregate_block(Ah, so[s], so[s + 1], h.agg, amg_strength(prm, l), aggregate_threads(nsub)); });
     for (auto& x : th) x.join();
     for (int s = 0; s < nsub; ++s) h.csub[s + 1] = h.csub[s] + nagg[s];
-    for (int s = 0; s < nsub; ++s)
-      for (int i = so[s]; i < so[s + 1]; ++i) h.agg[i] += h.csub[s];
+    for (int s = 1; s < nsub; ++s) {       // (block 0 keeps its numbers)
+      const int off = h.csub[s];
+      parallel_rows(so[s + 1] - so[s], [&](int a0, int a1) {
+        for (int i = so[s] + a0; i < so[s] + a1; ++i) h.agg[i] += off;
+      });
+    }
     h.nc = h.csub[nsub];
     if (h.nc >= n) h.last = true;
   }
+  if (getenv("GENEO_DEBUG") && Ah.n > 500000)
+    fprintf(stderr, "[amg/host] level %d, %d rows: diagonal + bound %.3f s, aggregation %.3f s\n", l, Ah.n,
+            std::chrono::duration<double>(t_hp1 - t_hp0).count(),
+            std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t_hp1).count());
   return h;
 }
 

@@ -849,7 +849,9 @@ int PC::setup(const double* b_dev) {
         if (!getenv("GENEO_AMG_HOST")) {
           AmgLevelHostPart l0;
           const bool have0 = pre_neu.valid();
+          const auto t_w0 = clk::now();
           if (have0) l0 = pre_neu.get();
+          if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] waited %.3f s for the fine level's host part (diagonal, aggregates)\n", secs(t_w0, clk::now()));
           built = amgN->build_on_device(h_neuL, suboff, apN, eig_block_max(), &neuL, have0 ? &l0 : nullptr);
         }
         if (!built) {
