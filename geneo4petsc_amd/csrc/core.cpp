@@ -333,26 +333,31 @@ int PC::build_layout() {
   std::sort(hmap.begin(), hmap.end());
   const bool ident = (nown == N);
   std::vector<int> l2e(nL);
-  for (int s = 0; s < ns; ++s) {
+  {
+    // one pass over the local space, whatever the subdomains (a parallel loop per subdomain spawned 8 x 16 threads)
     std::atomic<int> bad{0};      // 1: global index out of range, 2: neither owned nor in the halo plan
-    const std::vector<int>& l2g = subs[s].l2g;
-    const int off = suboff[s];
-    parallel_ranges((int64_t)l2g.size(), [&](int64_t i0, int64_t i1) {
-      for (int64_t i = i0; i < i1; ++i) {
-        const int g = l2g[i];
-        int e = -1;
-        if (g < 0 || g >= N) { bad = 1; return; }
-        if (ident) e = g;
-        else {
-          auto it = std::lower_bound(owned.begin(), owned.end(), g);
-          if (it != owned.end() && *it == g) e = (int)(it - owned.begin());
+    parallel_ranges((int64_t)nL, [&](int64_t i0, int64_t i1) {
+      int s = (int)(std::upper_bound(suboff.begin(), suboff.end(), (int)i0) - suboff.begin()) - 1;
+      for (int64_t i = i0; i < i1;) {
+        while (s + 1 < ns && i >= suboff[s + 1]) ++s;
+        const std::vector<int>& l2g = subs[s].l2g;
+        const int64_t e1 = std::min<int64_t>(i1, suboff[s + 1]);
+        for (; i < e1; ++i) {
+          const int g = l2g[i - suboff[s]];
+          int e = -1;
+          if (g < 0 || g >= N) { bad = 1; return; }
+          if (ident) e = g;
           else {
-            auto h = std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(g, -1));
-            if (h == hmap.end() || h->first != g) { bad = 2; return; }
-            e = nown + h->second;
+            auto it = std::lower_bound(owned.begin(), owned.end(), g);
+            if (it != owned.end() && *it == g) e = (int)(it - owned.begin());
+            else {
+              auto h = std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(g, -1));
+              if (h == hmap.end() || h->first != g) { bad = 2; return; }
+              e = nown + h->second;
+            }
           }
+          l2e[i] = e;
         }
-        l2e[off + i] = e;
       }
     });
     if (bad == 1) return fail("GenEO preconditioner: global index out of range");
@@ -618,7 +623,9 @@ int PC::finish_amg1() {
 int PC::setup(const double* b_dev) {
   // a second set-up of the same PC (or a retry after a failed one) first releases everything the previous one
   // allocated; the clock of setupTime starts after that release
+  const auto t_rel = clk::now();
   free_all();
+  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] release of the previous set-up (outside setupTime) %.4f s\n", secs(t_rel, clk::now()));
   info = Info();
   (void)amg_null_pivots_take();
   auto t0 = clk::now();
