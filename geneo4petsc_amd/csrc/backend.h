@@ -70,12 +70,14 @@ struct Csr {
   bool col_scaled = false;     // the values already carry the column scaling the EPI_PRE epilogue would apply (A diag(dinv))
   bool fine = false;           // a subdomain-level (fine) operator: its launches are the ones bench.py's in-situ timer samples
   // single-precision companion of the sliced layout (preconditioner use only: the V-cycle of the local solves): values as
-  // float, columns as 16-bit offsets from the slice's lowest column, same sl_ptr -- 6 bytes per entry instead of 12.
-  // lp_col / lp_base stay null when a slice spans more than 65535 columns (the kernels then read sl_col: 8 bytes per
+  // float, columns as 16-bit offsets from the slice's column bases, same sl_ptr -- 6 bytes per entry instead of 12.
+  // A slice has one base (its lowest column) or, when it spans more than 65535 columns (a 64-row slice of a 187^3 block:
+  // 70 002), two: the first ks entries of every row count from the first, the others from the second.
+  // lp_col / lp_base stay null when two bases are not enough either (the kernels then read sl_col: 8 bytes per
   // entry); all three are null when the matrix is not on the sliced path.
   float* lp_val = nullptr;
   unsigned short* lp_col = nullptr;
-  int* lp_base = nullptr;      // nslice
+  int* lp_base = nullptr;      // 4 x nslice: {b0, b1, ks, -} per slice (ks = INT_MAX: one base)
   int vec_lpr = 0;             // > 0: long / ragged rows (restriction, coarse Galerkin operators): the SpMV runs the
                                // lanes-per-row CSR kernel with this many lanes per row instead of the slices
 };

@@ -503,11 +503,13 @@ __global__ __launch_bounds__(256) void k_sell_fill(const int* __restrict__ rowpt
     len = rowptr[i + 1] - a;
   }
   const bool use = (i < n) && len <= long_len;
-  // padding entries (value 0) point at a column NEAR the slice's own -- the row's first one, or for an empty row / the
-  // rows past the end of the last slice the entry just before: the x gathers stay local and the slice's column span
-  // (16-bit offsets of the single-precision companion) is not widened by the padding
+  // padding entries (value 0) point at a column NEAR the slice's own -- the row's LAST one (its first one for a long row
+  // that is not stored here), or for an empty row / the rows past the end of the last slice the entry just before: the
+  // x gathers stay local and the slice's column span (16-bit offsets of the single-precision companion) is not widened
+  // by the padding.  The last column rather than the first: the padding sits behind the row's entries, and a slice that
+  // needs two column bases (k_lp_base) splits its entries by position -- low columns first, high columns last.
   int padc = 0;
-  if (i < n && len > 0) padc = col[a];
+  if (i < n && len > 0) padc = use ? col[a + len - 1] : col[a];
   else if (n > 0 && rowptr[n] > 0) {
     const int k = (i < n) ? a : rowptr[n];
     padc = col[k > 0 ? k - 1 : 0];
@@ -1681,6 +1683,10 @@ __global__ __launch_bounds__(256) void k_spmv_lds(const int* __restrict__ rowblk
   }
 }
 
+// Column bases of the 16-bit column offsets (see k_lp_base): {b0, b1, ks, -} per slice, one 16-byte load.
+__device__ __forceinline__ int4 lp_base_of(const int* __restrict__ base, int s) {
+  return base ? reinterpret_cast<const int4*>(base)[s] : int4{0, 0, 0x7fffffff, 0};
+}
 // Sliced kernel: one wave per 64-row slice, lane i owns row i.  Per k the wave issues one coalesced
 // 512-B val load, one 256-B col load and one x gather whose 64 addresses are the k-th neighbours of
 // 64 consecutive rows (contiguous for stencil-like matrices) -- no LDS round trip, no barrier.
@@ -1699,24 +1705,25 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ s
   if (t >= nwb || s >= nslice) return;
   const int l = threadIdx.x & 63;
   const int64_t a = sl_ptr[s], b = sl_ptr[s + 1];
-  const int cb = cbase ? cbase[s] : 0;
+  const int4 cb = lp_base_of(cbase, s);       // {b0, b1, ks}: entries k < ks count from b0, the others from b1
   double acc[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
   int64_t e = a + l;
-  for (; e + 64 * (UNR - 1) < b; e += 64 * UNR) {
+  int k = 0;
+  for (; e + 64 * (UNR - 1) < b; e += 64 * UNR, k += UNR) {
     int c[UNR];
     double v[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      c[u] = cb + (int)(NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u]);
+      c[u] = (k + u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u]);
       v[u] = NT ? __builtin_nontemporal_load(val + e + 64 * u) : val[e + 64 * u];
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) acc[u] += v[u] * x[c[u]];
   }
-  for (; e < b; e += 64) {
-    const int c0 = cb + (int)(NT ? __builtin_nontemporal_load(col + e) : col[e]);
+  for (; e < b; e += 64, ++k) {
+    const int c0 = (k < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e) : col[e]);
     const double v0 = NT ? __builtin_nontemporal_load(val + e) : val[e];
     acc[0] += v0 * x[c0];
   }
@@ -1743,18 +1750,19 @@ __global__ __launch_bounds__(256) void k_spmv_sell_p8(const int64_t* __restrict_
   if (t >= nwb || s >= nslice) return;
   const int l = threadIdx.x & 63;
   const int64_t a = sl_ptr[s], b = sl_ptr[s + 1];
-  const int cb = cbase ? cbase[s] : 0;
+  const int4 cb = lp_base_of(cbase, s);
   double acc0 = 0.0, acc1 = 0.0;
-  for (int64_t e = a + l; e < b; e += 64 * 8) {
+  int k = 0;
+  for (int64_t e = a + l; e < b; e += 64 * 8, k += 8) {
     int c[8];
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const bool ok = e + 64 * u < b;
-      c[u] = cb;
+      c[u] = cb.x;
       v[u] = 0.0;
       if (ok) {
-        c[u] = cb + (int)(NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u]);
+        c[u] = (k + u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e + 64 * u) : col[e + 64 * u]);
         v[u] = NT ? __builtin_nontemporal_load(val + e + 64 * u) : val[e + 64 * u];
       }
     }
@@ -2023,38 +2031,81 @@ void spmv_profile_stop(double* ms_sum, double* bytes_sum, long long* nsampled, l
 // (col, val) of the slices at 6 bytes per entry for the V-cycle of the local solves: the preconditioner of an FP64 PCG
 // needs its operator to a few digits only, and its passes over the fine and first coarse matrices are pure HBM streams.
 // Arithmetic stays FP64 (values are widened on load), vectors stay FP64.
+// Column bases of a slice: 16-bit offsets need the columns of a slice within 65 536 of a base.  One base (the slice's
+// lowest column) is enough while a 64-row slice of a grid block spans less than that; a 64-row slice of a 187^3 block
+// (one subdomain per GPU at 368^3 / 8) spans 2 x 187^2 + 64 = 70 002 columns.  Such a slice gets TWO bases: the entries
+// k < ks of every row (the slice's first ks stored columns, 64 entries each) count from b0, the others from b1 -- rows
+// hold their columns in ascending order, so the low neighbours sit in the first entries and the high ones in the last.
+// ks is the largest split the first base allows (greedy: the second group is then as small as it can be), wave-uniform
+// in the kernels that read it.  base4[s] = {b0, b1, ks, 0}; ks = INT_MAX when one base does.  `limit` is 65535
+// (GENEO_LP_SPAN_MAX lowers it so that small test cases take the two-base and the 32-bit paths).
+__device__ __forceinline__ int lp_wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int lp_wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
 __global__ __launch_bounds__(256) void k_lp_base(int ns, const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
-                                                 int* __restrict__ base, int* __restrict__ fail) {
+                                                 int4* __restrict__ base, int* __restrict__ fail, int limit,
+                                                 int* __restrict__ nsplit) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= ns) return;
   const int l = threadIdx.x & 63;
+  const int64_t a = sl_ptr[s];
+  const int wd = (int)((sl_ptr[s + 1] - a) >> 6);
   int lo = 0x7fffffff, hi = 0;
-  for (int64_t e = sl_ptr[s] + l; e < sl_ptr[s + 1]; e += 64) {
-    const int c = sl_col[e];
+  for (int k = 0; k < wd; ++k) {
+    const int c = sl_col[a + 64 * (int64_t)k + l];
     lo = c < lo ? c : lo;
     hi = c > hi ? c : hi;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int lo2 = __shfl_xor(lo, o, 64), hi2 = __shfl_xor(hi, o, 64);
-    lo = lo2 < lo ? lo2 : lo;
-    hi = hi2 > hi ? hi2 : hi;
+  lo = lp_wave_min(lo);
+  hi = lp_wave_max(hi);
+  if (lo == 0x7fffffff) lo = 0;          // empty slice
+  int b1 = lo, ks = 0x7fffffff;
+  if (hi - lo > limit) {
+    ks = wd;
+    for (int k = 0; k < wd; ++k) {       // first entry index whose columns leave the first base's window
+      const int mx = lp_wave_max(sl_col[a + 64 * (int64_t)k + l]);
+      if (mx - lo > limit) { ks = k; break; }
+    }
+    int lo2 = 0x7fffffff, hi2 = 0;
+    for (int k = ks; k < wd; ++k) {
+      const int c = sl_col[a + 64 * (int64_t)k + l];
+      lo2 = c < lo2 ? c : lo2;
+      hi2 = c > hi2 ? c : hi2;
+    }
+    lo2 = lp_wave_min(lo2);
+    hi2 = lp_wave_max(hi2);
+    b1 = lo2;
+    if (l == 0) {
+      if (hi2 - lo2 > limit) atomicExch(fail, 1);
+      else atomicAdd(nsplit, 1);
+    }
   }
-  if (l == 0) {
-    if (lo == 0x7fffffff) lo = 0;          // empty slice
-    base[s] = lo;
-    if (hi - lo > 65535) atomicExch(fail, 1);
-  }
+  if (l == 0) base[s] = int4{lo, b1, ks, 0};
 }
 __global__ __launch_bounds__(256) void k_lp_fill(int ns, const int64_t* __restrict__ sl_ptr, const int* __restrict__ sl_col,
-                                                 const double* __restrict__ sl_val, const int* __restrict__ base,
+                                                 const double* __restrict__ sl_val, const int4* __restrict__ base,
                                                  unsigned short* __restrict__ c16, float* __restrict__ v32) {
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= ns) return;
   const int l = threadIdx.x & 63;
-  const int b = c16 ? base[s] : 0;
-  for (int64_t e = sl_ptr[s] + l; e < sl_ptr[s + 1]; e += 64) {
-    if (c16) c16[e] = (unsigned short)(sl_col[e] - b);
+  const int4 b = c16 ? base[s] : int4{0, 0, 0x7fffffff, 0};
+  const int64_t a = sl_ptr[s];
+  int k = 0;
+  for (int64_t e = a + l; e < sl_ptr[s + 1]; e += 64, ++k) {
+    if (c16) c16[e] = (unsigned short)(sl_col[e] - (k < b.z ? b.x : b.y));
     v32[e] = (float)sl_val[e];
   }
 }
@@ -2065,24 +2116,31 @@ bool csr_make_lp(Csr& a, const Csr* index_owner) {
     a.lp_col = index_owner->lp_col;
     a.lp_base = index_owner->lp_base;
   } else {
-    a.lp_base = (int*)alloc(sizeof(int) * (size_t)a.nslice);
-    int* dfail = (int*)alloc(sizeof(int));
-    HIPCHK(hipMemsetAsync(dfail, 0, sizeof(int), g_stream));
-    hipLaunchKernelGGL(k_lp_base, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.nslice, a.sl_ptr, a.sl_col, a.lp_base,
-                       dfail);
-    int hfail = 0;
-    d2h(&hfail, dfail, sizeof(int));
+    const char* lim_env = getenv("GENEO_LP_SPAN_MAX");       // read per call: tests lower it for one set-up
+    int limit = lim_env ? atoi(lim_env) : 65535;
+    if (limit < 1 || limit > 65535) limit = 65535;
+    a.lp_base = (int*)alloc(sizeof(int4) * (size_t)a.nslice);
+    int* dfail = (int*)alloc(2 * sizeof(int));
+    HIPCHK(hipMemsetAsync(dfail, 0, 2 * sizeof(int), g_stream));
+    hipLaunchKernelGGL(k_lp_base, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.nslice, a.sl_ptr, a.sl_col,
+                       (int4*)a.lp_base, dfail, limit, dfail + 1);
+    int hfail[2] = {0, 0};
+    d2h(hfail, dfail, 2 * sizeof(int));
     dfree(dfail);
-    if (hfail) {             // a slice spans more than 65535 columns: float values over the 32-bit columns (8 B per entry)
+    if (hfail[0]) {          // a slice needs more than two bases: float values over the 32-bit columns (8 B per entry)
       dfree(a.lp_base);
       a.lp_base = nullptr;
     } else {
       a.lp_col = (unsigned short*)alloc(sizeof(unsigned short) * (size_t)std::max<int64_t>(1, a.sl_nnz));
     }
+    if (getenv("GENEO_DEBUG") && (hfail[0] || hfail[1]))
+      fprintf(stderr, "[lp] %d-row matrix, %d slices: %s (span limit %d)\n", a.n, a.nslice,
+              hfail[0] ? "32-bit columns kept (a slice needs more than two bases)"
+                       : (std::to_string(hfail[1]) + " slices with two column bases").c_str(), limit);
   }
   a.lp_val = (float*)alloc(sizeof(float) * (size_t)std::max<int64_t>(1, a.sl_nnz));
   hipLaunchKernelGGL(k_lp_fill, dim3((a.nslice + 3) / 4), dim3(256), 0, g_stream, a.nslice, a.sl_ptr, a.sl_col, a.sl_val,
-                     a.lp_base, (index_owner || !a.lp_col) ? (unsigned short*)nullptr : a.lp_col, a.lp_val);
+                     (const int4*)a.lp_base, (index_owner || !a.lp_col) ? (unsigned short*)nullptr : a.lp_col, a.lp_val);
   return true;
 }
 // WPS = 1: one wave per slice (four slices per workgroup), WPS = 4: one workgroup per slice (wide slices), as the FP64
@@ -2108,7 +2166,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
     if (s >= nslice) return;
   }
   const int64_t a = sl_ptr[s], e1 = sl_ptr[s + 1];
-  const int cb = base ? base[s] : 0;     // 16-bit columns are offsets from the slice's lowest column
+  const int4 cb = lp_base_of(base, s);   // 16-bit columns are offsets from the slice's bases (k_lp_base)
   const double* __restrict__ xin = (EPI == EPI_PRE) ? b : x;
   // The epilogue's own operands do not depend on the product: their loads are issued HERE, in front of the matrix stream,
   // instead of after the last gather has come back (one dependent memory round trip less per wave; a wave holds one
@@ -2127,19 +2185,20 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
 #pragma unroll
   for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
   int64_t e = a + (WPS == 1 ? 0 : 64 * wv) + l;
-  for (; e + STEP * (UNR - 1) < e1; e += STEP * UNR) {
+  int k = (WPS == 1 ? 0 : wv);            // entry index of e within its row
+  for (; e + STEP * (UNR - 1) < e1; e += STEP * UNR, k += WPS * UNR) {
     int c[UNR];
     double v[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      c[u] = cb + (int)col[e + STEP * u];
+      c[u] = (k + WPS * u < cb.z ? cb.x : cb.y) + (int)col[e + STEP * u];
       v[u] = (double)val[e + STEP * u];
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) acc[u] += v[u] * ((EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]]);
   }
-  for (; e < e1; e += STEP) {
-    const int c0 = cb + (int)col[e];
+  for (; e < e1; e += STEP, k += WPS) {
+    const int c0 = (k < cb.z ? cb.x : cb.y) + (int)col[e];
     acc[0] += (double)val[e] * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
   }
   double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);

@@ -212,6 +212,20 @@ def test_vcycle_storage_and_form_do_not_change_the_result(lib, precision, post, 
     assert info["amg_levels"] >= 3
 
 
+@pytest.mark.parametrize("span_max", ["250", "60"])
+def test_two_base_and_32bit_column_layouts_of_the_companions_in_a_solve(lib, span_max, monkeypatch, capfd):
+    """The single-precision companions of the V-cycle with their 16-bit column offsets limited to a span of 250 (the
+    12^3 blocks' slices span 352 columns: two bases per slice, as a 187^3 block's do at the real limit of 65535) and of
+    60 (32-bit columns kept): same counts as the oracle, same solution."""
+    monkeypatch.setenv("GENEO_LP_SPAN_MAX", span_max)
+    monkeypatch.setenv("GENEO_DEBUG", "1")
+    argv = ["-geneo_lvl", "SRAS,1", "-geneo_tau", "0.35", "-geneo_cut", "12", "-ksp_type", "gmres", "-dls1_pc_type", "amg",
+            "-els2_pc_type", "amg", "-amg_coarse_size", "100"] + TIGHT + ["-els2_eps_tol", "1e-12"]
+    cases.compare_with_oracle(lib, 20, (2, 2, 2), 2, argv)
+    err = capfd.readouterr().err
+    assert ("slices with two column bases" if span_max == "250" else "32-bit columns kept") in err
+
+
 def test_large_coarse_operator_blocked_cholesky(lib):
     """dimE = 312 and a 64-column LOBPCG block (192-column Gram / block update kernels); E through the blocked Cholesky."""
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.9", "-geneo_cut", "39", "-ksp_type", "cg"] + TIGHT

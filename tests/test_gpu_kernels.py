@@ -170,11 +170,16 @@ def test_wide_slice_kernels(lib, m, n, per_row):
 
 @pytest.mark.parametrize("n,per_row,kind,half_width", [(5000, 8, 1, 20000), (300000, 6, 1, 20000), (300000, 6, 1, 150000),
                                                        (5000, 30, 101, 2000), (640, 45, 101, 300)])
-def test_single_precision_companion(lib, n, per_row, kind, half_width):
+@pytest.mark.parametrize("span_max", [None, 2500, 450, 40])
+def test_single_precision_companion(lib, n, per_row, kind, half_width, span_max, monkeypatch):
     """k_spmv_sell_lp (wave-per-slice and workgroup-per-slice forms): the product and the four epilogues against the
     FP64 algebra on the matrix ROUNDED to float (the companion stores float values, arithmetic is FP64: agreement to
-    1e-12), and against the unrounded matrix to single precision."""
+    1e-12), and against the unrounded matrix to single precision.  span_max lowers the column span a 16-bit offset may
+    cover (GENEO_LP_SPAN_MAX, 65535 by default) so that these small matrices take the two-base layout (k_lp_base: slices
+    of the 2000- and 300-wide bands at 2500 / 450) and the 32-bit fallback (40) as well: same results in every layout."""
     from geneo4petsc_amd.pc import Spmv
+    if span_max is not None:
+        monkeypatch.setenv("GENEO_LP_SPAN_MAX", str(span_max))
     a = _band_csr(n, per_row, half_width, 31)
     assert np.diff(a.indptr).max() <= 64
     a32 = a.copy()
@@ -215,8 +220,45 @@ def test_spmv_with_16bit_column_offsets(lib):
     np.testing.assert_array_equal(y16, y32)     # same entries in the same order: bitwise
 
 
+def test_two_column_bases_for_slices_wider_than_16_bits(lib, capfd, monkeypatch):
+    """A 64-row slice of one 187^3 block per GPU (the metric's layout: 368^3 on 8 GPUs) spans 2 x 187^2 + 64 = 70 002
+    columns -- more than one 16-bit base covers.  Such slices carry TWO bases (k_lp_base: the first ks entries of every
+    row count from the first, the others from the second), here on a 7-point pattern with that plane distance and with
+    the short rows of block faces (padding behind the row's entries).  The FP64 SpMV over the 16-bit offsets equals the
+    32-bit-column kernel to the bit, the single-precision companion equals the float-rounded matrix to 1e-12, and the
+    debug line says that the two-base layout (not the 32-bit fallback) is what ran."""
+    from geneo4petsc_amd.pc import Spmv
+    n, nx, plane = 700000, 187, 187 * 187
+    rng = np.random.default_rng(77)
+    i = np.arange(n)
+    rows, cols = [i], [i]
+    for off, keep in ((-plane, i >= plane), (plane, i + plane < n), (-nx, (i % plane) >= nx), (nx, (i % plane) < plane - nx),
+                      (-1, i % nx != 0), (1, i % nx != nx - 1)):
+        keep = keep & (i + off >= 0) & (i + off < n)
+        rows.append(i[keep]); cols.append(i[keep] + off)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    a = sp.csr_matrix((rng.random(len(rows)) + 0.5, (rows, cols)), shape=(n, n)).tocsr()
+    a.sort_indices()
+    assert a.nnz * 12 > 48e6           # large enough for the non-temporal FP64 kernel that reads the 16-bit offsets
+    a32 = a.copy()
+    a32.data = a32.data.astype(np.float32).astype(np.float64)
+    x, b = rng.random(n) - 0.5, rng.random(n) - 0.5
+    monkeypatch.setenv("GENEO_DEBUG", "1")
+    h = Spmv(a, lib)
+    y32 = h.apply(x)
+    ylp = h.fused_single(0, X=x)[0]            # builds the companion
+    y16 = h.apply(x)
+    err = capfd.readouterr().err
+    assert "slices with two column bases" in err and "32-bit columns kept" not in err, err
+    np.testing.assert_allclose(y32, a @ x, rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(y16, y32)
+    np.testing.assert_allclose(ylp, a32 @ x, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(h.fused_single(1, X=x, B=b)[0], b - a32 @ x, rtol=1e-12, atol=1e-13)
+
+
 def test_single_precision_companion_keeps_32bit_columns_for_wide_slices(lib):
-    """A slice whose columns span more than 65535 keeps its 32-bit columns (float values only)."""
+    """A slice whose columns two bases cannot cover either (row 0: columns 0 and n - 1 with the other rows' diagonal
+    entries and padding between them) keeps its 32-bit columns (float values only)."""
     from geneo4petsc_amd.pc import Spmv
     n = 70000
     a = (sp.diags(np.arange(1.0, n + 1)) + sp.csr_matrix((np.full(1, 0.25), ([0], [n - 1])), shape=(n, n))).tocsr()
