@@ -2145,7 +2145,9 @@ bool csr_make_lp(Csr& a, const Csr* index_owner) {
 }
 // WPS = 1: one wave per slice (four slices per workgroup), WPS = 4: one workgroup per slice (wide slices), as the FP64
 // kernels k_spmv_sell_epi / k_spmv_sell_wide above; summation order fixed.
-template <int EPI, int WPS, typename COLT>
+// NT: the once-read (col, val) stream of a LARGE companion is marked non-temporal, as in k_spmv_sell (the vectors of the
+// cycle, not the matrix, are what the caches should keep); a hint only -- same loads, same arithmetic.
+template <int EPI, int WPS, typename COLT, bool NT>
 __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict__ sl_ptr, int nslice, int n,
                                                       const COLT* __restrict__ col, const float* __restrict__ val,
                                                       const int* __restrict__ base, const double* __restrict__ x,
@@ -2191,15 +2193,16 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
     double v[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      c[u] = (k + WPS * u < cb.z ? cb.x : cb.y) + (int)col[e + STEP * u];
-      v[u] = (double)val[e + STEP * u];
+      c[u] = (k + WPS * u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e + STEP * u) : col[e + STEP * u]);
+      v[u] = (double)(NT ? __builtin_nontemporal_load(val + e + STEP * u) : val[e + STEP * u]);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) acc[u] += v[u] * ((EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]]);
   }
   for (; e < e1; e += STEP, k += WPS) {
-    const int c0 = (k < cb.z ? cb.x : cb.y) + (int)col[e];
-    acc[0] += (double)val[e] * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
+    const int c0 = (k < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e) : col[e]);
+    const double v0 = (double)(NT ? __builtin_nontemporal_load(val + e) : val[e]);
+    acc[0] += v0 * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
   }
   double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   if (WPS == 4) {
@@ -2238,9 +2241,16 @@ static void spmv_lp_launch(const Csr& a, const double* x, double* y, const doubl
   const double* cs = (EPI == EPI_PRE && !a.col_scaled) ? dinv : nullptr;
   const int per = (a.nslice + 7) / 8;
   const int perw = ((a.nslice + 3) / 4 + 7) / 8;
-#define LP_LAUNCH(WPS, COLT, colp, grid)                                                                              \
-  hipLaunchKernelGGL((k_spmv_sell_lp<EPI, WPS, COLT>), dim3(grid), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, colp, \
+  static const bool nt_off = getenv("GENEO_LP_NO_NT") != nullptr;
+  const bool nt = !nt_off && (double)a.sl_nnz * ebytes >= 24e6;
+#define LP_LAUNCH2(WPS, COLT, colp, grid, NT)                                                                          \
+  hipLaunchKernelGGL((k_spmv_sell_lp<EPI, WPS, COLT, NT>), dim3(grid), dim3(256), 0, g_stream, a.sl_ptr, a.nslice, a.n, colp, \
                      a.lp_val, a.lp_base, x, y, b, z, dinv, w, cs)
+#define LP_LAUNCH(WPS, COLT, colp, grid)          \
+  do {                                            \
+    if (nt) LP_LAUNCH2(WPS, COLT, colp, grid, true); \
+    else LP_LAUNCH2(WPS, COLT, colp, grid, false);   \
+  } while (0)
   if (sell_wide(a)) {
     if (a.lp_col) LP_LAUNCH(4, unsigned short, a.lp_col, per * 8);
     else LP_LAUNCH(4, int, a.sl_col, per * 8);
@@ -2249,6 +2259,7 @@ static void spmv_lp_launch(const Csr& a, const double* x, double* y, const doubl
     else LP_LAUNCH(1, int, a.sl_col, perw * 8);
   }
 #undef LP_LAUNCH
+#undef LP_LAUNCH2
 }
 void spmv_lp(const Csr& a, const double* x, double* y) { spmv_lp_launch<EPI_NONE>(a, x, y, nullptr, nullptr, nullptr, 0.0); }
 void spmv_fused_lp(const Csr& a, int epi, const double* x, double* y, const double* b, double* z, const double* dinv, double w) {
