@@ -2645,7 +2645,7 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
                                                         const double* __restrict__ X, int ldx, double* __restrict__ Y, int ldy,
                                                         const double* __restrict__ pre, const double* __restrict__ post,
                                                         const double* __restrict__ B, int ldb, double* __restrict__ Z, int ldz,
-                                                        const double* __restrict__ dinv, double w) {
+                                                        const double* __restrict__ dinv, double w, int nt /* large matrix: (col, val) and Y streamed non-temporally */) {
   typedef spmm_d2 d2;
   constexpr int KC = 16;             // entries per row staged per chunk
   constexpr int RS = 64 / LG;        // rows per wave-wide load
@@ -2690,8 +2690,8 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
     if (k0 > 0) __syncthreads();
     for (int k = wave; k < kc; k += 4) {
       const int64_t e = base + (int64_t)64 * (k0 + k) + lane;
-      const int c = sl_col[e];
-      double v = sl_val[e];
+      const int c = nt ? __builtin_nontemporal_load(sl_col + e) : sl_col[e];
+      double v = nt ? __builtin_nontemporal_load(sl_val + e) : sl_val[e];
       if (pre) v *= pre[c];
       lc[k * 64 + lane] = c;
       lv[k * 64 + lane] = v;
@@ -2736,7 +2736,8 @@ __global__ __launch_bounds__(256) void k_spmm_sell_wide(const int64_t* __restric
       if (Z) *reinterpret_cast<d2*>(Z + r * ldz + 2 * q) = (w * e_d[u]) * e_b[u];
       out = e_b[u] - w * a2;
     }
-    *reinterpret_cast<d2*>(Y + r * ldy + 2 * q) = out;
+    if (nt) __builtin_nontemporal_store(out, reinterpret_cast<d2*>(Y + r * ldy + 2 * q));
+    else *reinterpret_cast<d2*>(Y + r * ldy + 2 * q) = out;
   }
 }
 
@@ -2765,7 +2766,9 @@ static bool spmm_sell_launch(const Csr& a, const double* X, int ldx, double* Y, 
     const int per = (a.nslice + 7) / 8;
 #define SELLW(L)                                                                                                           \
   hipLaunchKernelGGL((k_spmm_sell_wide<L, EPI>), dim3(per * 8), dim3(256), 0, g_stream, a.sl_ptr, a.sl_col, a.sl_val, a.n, \
-                     a.nslice, X, ldx, Y, ldy, pre, post, B, ldb, Z, ldz, dinv, w)
+                     a.nslice, X, ldx, Y, ldy, pre, post, B, ldb, Z, ldz, dinv, w, wide_nt)
+    static const bool wide_nt_off = getenv("GENEO_SPMM_WIDE_NO_NT") != nullptr;
+    const int wide_nt = (!wide_nt_off && sell_nt(a)) ? 1 : 0;
     if (m == 16) { SELLW(8); return true; }
     if (m == 32) { SELLW(16); return true; }
 #undef SELLW
