@@ -11,13 +11,17 @@ One "step" = one full pass of the hot path on the resident subdomain matrices:
     KSPSetUp  (setUpGenEOPC: level-1 set-up, LOBPCG eigensolves, Z, E = Z^T A Z, factorisation)
   + KSPSolve  (PCG, every iteration = MATIS SpMV + applyGenEOPC with coarse correction)
 
-Workloads (3-D 7-point Laplacian of the reference's tst/laplacian generator, kappa = 1, eps = 1e-4, overlap 2,
+Workload (3-D 7-point Laplacian of the reference's tst/laplacian generator, kappa = 1, eps = 1e-4, overlap 2,
 -geneo_lvl SRAS,1 -geneo_cut 20, tau 0.35, PCG rtol 1e-5):
-  N = 1   BASELINE configs[1] size: 126^3 = 2.0 M DoF, split into 8 overlapping subdomains on the one GPU so that the
-          whole two-level method (eigensolves, coarse space, RAS apply) runs.
-  N > 1   the metric's configuration (BASELINE configs[2], SURVEY 8d "config 3"): 184^3 DoF per GPU, ONE subdomain per GPU
-          (--subdomains-per-gpu 1) -- N = 8 is 368^3 = 49.8 M DoF in 8 subdomains.  Weak scaling.  Halo exchange and
+  --scaling strong (default): THE METRIC'S CONFIGURATION AT EVERY N (BASELINE configs[2], SURVEY 8d "config 3"): the
+          368^3 = 49.8 M DoF grid in 8 subdomains (2 x 2 x 2 blocks), 8 / 4 / 2 / 1 subdomains per GPU at N = 1 / 2 / 4 / 8
+          -- the reference's layout (one subdomain per MPI rank, global problem fixed, src/geneo4PETSc.cpp:604) folded
+          onto fewer GPUs, so that N = 1, 2, 4, 8 is ONE curve.  On one GPU the eight 6.5 M-row eigensolves run group by
+          group under a device-memory budget (-geneo_eig_mem_gb: the matrices and hierarchies of all eight stay resident,
+          the LOBPCG blocks of one group at a time; results identical to the all-at-once path).  N > 1: halo exchange and
           all-reduces over RCCL (C++ transport inside libgeneopc, csrc/comm_rccl.cpp).
+  --scaling weak: the round-1..3 lines -- N = 1: BASELINE configs[1] size, 126^3 = 2.0 M DoF in 8 subdomains on the one
+          GPU (--n 126); N > 1: 184^3 DoF and ONE subdomain per GPU.
 
 `value` = CSR SpMV GB/s (the metric's bandwidth figure): algorithmic bytes of the fine-level SpMV launches issued
 inside the timed steps / their HIP-event time on the launch stream, summed over ranks.  Setup and solve seconds are
@@ -55,11 +59,14 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="strong (default): the metric's 368^3 grid in 8 subdomains at every N, 8 / N subdomains per GPU; "
+                         "weak: 126^3 in 8 subdomains at N = 1, 184^3 and one subdomain per GPU at N > 1 (rounds 1-3)")
     ap.add_argument("--n-per-gpu", type=int, default=0,
-                    help="grid points per side per GPU; 0 = 126 at N = 1 (2.0 M DoF), 184 at N > 1 (N = 8: 368^3 = 49.8 M)")
-    ap.add_argument("--subdomains-per-gpu", type=int, default=0, choices=(0, 1, 8),
-                    help="0 = 8 at N = 1, 1 at N > 1 (the metric's 8 subdomains on 8 GPUs)")
-    ap.add_argument("--n", type=int, default=0, help="override the global grid side")
+                    help="--scaling weak: grid points per side per GPU; 0 = 126 at N = 1 (2.0 M DoF), 184 at N > 1")
+    ap.add_argument("--subdomains-per-gpu", type=int, default=0, choices=(0, 1, 2, 4, 8),
+                    help="--scaling weak: 0 = 8 at N = 1, 1 at N > 1.  --scaling strong: always 8 / N")
+    ap.add_argument("--n", type=int, default=0, help="global grid side (--scaling strong: default 368)")
     ap.add_argument("--overlap", type=int, default=2)
     ap.add_argument("--lvl", default="SRAS,1", help="-geneo_lvl; SRAS keeps the RAS weighting and a CG-legal (symmetric) PC")
     ap.add_argument("--tau", type=float, default=0.35)
@@ -112,6 +119,17 @@ def geneo_argv(args):
 
 def workload(args, size):
     """(global grid side n, subdomain grid `parts`, subdomain -> rank map, subdomains per GPU)"""
+    if args.scaling == "strong":
+        if size not in (1, 2, 4, 8):
+            raise SystemExit("--scaling strong: 8 subdomains on 1, 2, 4 or 8 GPUs")
+        n = args.n or 368
+        parts, rg = (2, 2, 2), rank_grid(size)
+        sub_rank = np.zeros(8, dtype=np.int64)
+        for bk in range(2):
+            for bj in range(2):
+                for bi in range(2):          # block (bi, bj, bk) lives on the rank whose box of the rank grid holds it
+                    sub_rank[bi + 2 * (bj + 2 * bk)] = (bi * rg[0]) // 2 + rg[0] * ((bj * rg[1]) // 2 + rg[1] * ((bk * rg[2]) // 2))
+        return n, parts, sub_rank, 8 // size
     spg = args.subdomains_per_gpu or (8 if size == 1 else 1)
     npg = args.n_per_gpu or (126 if size == 1 else 184)
     n = args.n if args.n else int(round((npg ** 3 * size) ** (1.0 / 3.0)))
@@ -202,7 +220,14 @@ def cpu_baseline(args, doms, lib):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "csrc")])
     olib = C.CDLL(so)
     olib.oracle_num_threads.restype = C.c_int
-    a = sp.block_diag([d.a_dir for d in doms], format="csr")
+    # bounded sample: the local matrices of as many subdomains as stay under 8 M rows (368^3: one 6.5 M-row subdomain)
+    take, rows = [], 0
+    for d in doms:
+        if take and rows + d.a_dir.shape[0] > 8_000_000:
+            break
+        take.append(d)
+        rows += d.a_dir.shape[0]
+    a = sp.block_diag([d.a_dir for d in take], format="csr") if len(take) > 1 else take[0].a_dir.tocsr()
     rp, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
     x = np.random.default_rng(0).random(a.shape[0])
     y = np.zeros(a.shape[0])
@@ -218,8 +243,8 @@ def cpu_baseline(args, doms, lib):
     nbytes = a.nnz * 12 + (a.shape[0] + 1) * 4 + a.shape[0] * 16
     out["value"] = nbytes / dt / 1e9
     out["cores"] = int(olib.oracle_num_threads())
-    out["sample"] = "CSR SpMV of the same %d-row / %d-nnz local matrix, %d repetitions (C + OpenMP)" % (
-        a.shape[0], a.nnz, reps)
+    out["sample"] = "CSR SpMV of the %d-row / %d-nnz local matrix of %d of the rank's %d subdomains, %d repetitions (C + OpenMP)" % (
+        a.shape[0], a.nnz, len(take), len(doms), reps)
     # (2) the oracle's GenEO setup + PCG solve (exact LU local solves, ARPACK shift-invert at -els2_eps_tol) on a bounded sample
     #     of the same workload -- same operator, same options, smaller grid -- and the GPU library beside it
     try:
@@ -312,6 +337,7 @@ def one_rank_of(args):
     for _ in range(max(0, args.warmup - 1)):
         step()
     lib.GeneoKernelProfileStart(4, C.c_double(0.0))
+    lib.GeneoDeviceMemInfo(None, None, None, None, None, None, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
@@ -320,6 +346,7 @@ def one_rank_of(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.GeneoKernelProfileStop()
+    mem = device_memory(lib)
     its, reason, info = last
     kernels = kernel_table(lib, 1e3 * elapsed, args.steps)
     ms_sum, by_sum = C.c_double(0), C.c_double(0)
@@ -345,8 +372,8 @@ def one_rank_of(args):
     out = {
         "metric": "GenEO-PCG setup+solve sec and SpMV GB/s, 3D Laplacian 50M DoF, 1/2/4/8 GPUs",
         "value": gbs, "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "device_mem_peak_gb": mem["device_mem_peak_gb"], "device_memory": mem,
         "config": {"workload": "ONE RANK'S SHARE of the metric's configuration, alone on one GPU: subdomain %d of the 2x2x2 "
                                "decomposition of the %d^3 = %d DoF 7-pt Laplacian (reference tst/laplacian generator), overlap %d => "
                                "%d local rows, -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g; set-up = every "
@@ -422,6 +449,18 @@ def spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def device_memory(lib):
+    """device-memory figures of the bench line (GiB): high-water mark of the library's live blocks over the timed steps,
+    of live + parked in its caching allocator (the process's footprint on the card as the library sees it), and what
+    hipMemGetInfo reports for the card right now (used = total - free: includes torch's context and the caches)"""
+    v = [C.c_double(0) for _ in range(6)]
+    lib.GeneoDeviceMemInfo(*[C.byref(x) for x in v], 0)
+    g = 1073741824.0
+    live, live_peak, foot_peak, cached, free, total = [x.value / g for x in v]
+    return {"device_mem_peak_gb": live_peak, "device_mem_footprint_peak_gb": foot_peak, "device_mem_live_gb": live,
+            "allocator_cache_gb": cached, "hip_mem_used_gb": total - free, "hip_mem_total_gb": total}
+
+
 def kernel_table(lib, step_ms_total, n_steps):
     rows = []
     for cls, name, bound in KERNEL_CLASSES:
@@ -448,7 +487,7 @@ def spmv_hbm_resident(lib, doms):
     launches (k_axpby on two 40 M-element vectors), HIP events around every SpMV."""
     import scipy.sparse as sp
     from geneo4petsc_amd.pc import Spmv, DeviceVector
-    a = sp.block_diag([d.a_dir for d in doms], format="csr")
+    a = sp.block_diag([d.a_dir for d in doms], format="csr") if len(doms) > 1 else doms[0].a_dir.tocsr()
     h = Spmv(a, lib)
     x = DeviceVector.from_host(lib, np.random.default_rng(0).random(a.shape[0]))
     y = DeviceVector(lib, a.shape[0])
@@ -574,6 +613,7 @@ def main():
                                    "the same PC on cached device blocks"}
     # in-situ kernel timer: every 4th launch of each hot kernel class (fine-level SpMV / SpMM, MFMA Gram and update)
     lib.GeneoKernelProfileStart(4, C.c_double(0.0))
+    lib.GeneoDeviceMemInfo(None, None, None, None, None, None, 1)      # high-water marks of the timed steps alone
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -582,6 +622,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     lib.GeneoKernelProfileStop()
+    mem = device_memory(lib)
     its, reason, info = last
     kernels = kernel_table(lib, 1e3 * elapsed, args.steps)
     ms_sum, by_sum = C.c_double(0), C.c_double(0)
@@ -670,8 +711,10 @@ def main():
         out = {
             "metric": "GenEO-PCG setup+solve sec and SpMV GB/s, 3D Laplacian 50M DoF, 1/2/4/8 GPUs",
             "value": agg_gbs, "unit": "GB/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": args.scaling if args.workload == "laplacian" else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "device_mem_peak_gb": mem["device_mem_peak_gb"], "device_memory": mem, "eig_groups": info.get("eigGroups"),
             "transport_fallback": transport_fallback,      # not None: this is NOT a measurement of the C++ RCCL transport
             "config": {"workload": (wl_desc + ", -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e"
                                     % (args.lvl, args.cut, args.tau, args.eps_tol, args.rtol)) if wl_desc else
@@ -679,9 +722,12 @@ def main():
                                    "no 27-pt generator), %d^3 = %d DoF, %d subdomains (%d per GPU), overlap %d, "
                                    "-geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e; %s"
                                    % (n, n ** 3, nb, spg, args.overlap, args.lvl, args.cut, args.tau, args.eps_tol, args.rtol,
-                                      "N=1: BASELINE configs[1] size (126^3 = 2.0 M DoF) in 8 subdomains on the one GPU"
-                                      if size == 1 else
-                                      "N>1: the metric's configuration, 184^3 DoF and one subdomain per GPU (N=8: 368^3 = 49.8 M)"),
+                                      ("the metric's configuration (BASELINE configs[2]): the whole %d^3 grid in 8 subdomains on %d GPU%s, "
+                                       "eigensolves in %d group(s) under the device-memory budget" % (n, size, "" if size == 1 else "s", info.get("eigGroups") or 1))
+                                      if args.scaling == "strong" else
+                                      ("N=1: BASELINE configs[1] size (126^3 = 2.0 M DoF) in 8 subdomains on the one GPU"
+                                       if size == 1 else
+                                       "N>1: 184^3 DoF and one subdomain per GPU (N=8: 368^3 = 49.8 M), weak scaling")),
                        "workload_kind": args.workload, "workload_facts": wl_facts,
                        "local_rows": info_rows, "local_nnz": int(sum(d.a_neu.nnz for d in doms)),
                        "grid": n, "dof": ndof, "subdomains": nb, "subdomains_per_gpu": spg, "overlap": args.overlap,
@@ -719,17 +765,18 @@ def main():
                                     args.lvl: {"iterations": int(its), "converged": reason, "dimE": info["dimE"],
                                                "setup_s": setup_s, "solve_s": solve_s}}
         if size == 1 and not args.no_cpu_baseline and args.workload == "laplacian":
-            try:
-                roof["spmv_hbm_resident"] = spmv_hbm_resident(lib, doms)
-                roof["spmv_hbm_resident"]["frac"] = roof["spmv_hbm_resident"]["GBs"] / HBM_PEAK_GBS
-            except Exception as e:
-                roof["spmv_hbm_resident"] = {"error": repr(e)}
+            if spmv_ws <= 256 * 2 ** 20:     # only where the in-situ rate is cache-assisted
+                try:
+                    roof["spmv_hbm_resident"] = spmv_hbm_resident(lib, doms)
+                    roof["spmv_hbm_resident"]["frac"] = roof["spmv_hbm_resident"]["GBs"] / HBM_PEAK_GBS
+                except Exception as e:
+                    roof["spmv_hbm_resident"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline(args, doms, lib)
             if "parity_sample" in out["cpu_baseline"]:
                 out["parity_sample"] = out["cpu_baseline"].pop("parity_sample")
     pc.destroy()
     if rank == 0:
-        if size > 1 and not args.no_anchor:
+        if size > 1 and not args.no_anchor and args.scaling == "weak":
             # The weak-scaling curve compares N GPUs x (184^3, ONE subdomain each) with ... what on one GPU?  bench.py's N = 1
             # line is 126^3 in 8 subdomains (BASELINE configs[1]); the like-for-like anchor -- the SAME per-GPU DoF count on
             # one GPU, where the two-level method needs several subdomains -- is 184^3 in 8 subdomains, run here on rank 0's

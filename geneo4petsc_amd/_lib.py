@@ -35,7 +35,7 @@ class GeneoInfo(C.Structure):
                                           "lvl1ApplyPrjFSTimeLoc", "lvl2ApplyTimeLoc", "lvl2ApplyZtTimeLoc",
                                           "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")] + \
                [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double),
-                ("nullPivotsLoc", C.c_int)]
+                ("nullPivotsLoc", C.c_int), ("eigGroups", C.c_int)]
 
 
 class GeneoDomain(C.Structure):
@@ -142,6 +142,7 @@ SYMBOLS = {
     "GeneoSpmvProfileStart": (C.c_int, [C.c_int, C.c_double]),
     "GeneoSpmvProfileStop": (C.c_int, [c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoKernelProfileStart": (C.c_int, [C.c_int, C.c_double]),
+    "GeneoDeviceMemInfo": (C.c_int, [c_dbl_p] * 6 + [C.c_int]),
     "GeneoKernelProfileStop": (C.c_int, []),
     "GeneoKernelProfileGet": (C.c_int, [C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoSpmmApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -325,16 +325,30 @@ static double amg_strength(const AmgParams& prm, int level) {
   return prm.strength * std::pow(0.5, level);
 }
 
-static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
+// Jacobi scaling and Gershgorin bound of D^-1 A, PER SUBDOMAIN BLOCK.  Every use of dinv in the hierarchy is a smoothing
+// step w D^-1 with a weight w proportional to 1 / rho (prolongator smoothing 4 / (3 rho), damped Jacobi, Chebyshev), and the
+// kernels take ONE scalar w per level: the level keeps rho = the largest block's bound and a block with a smaller bound
+// rho_s gets its rows of dinv scaled by rho / rho_s, so that w dinv is that block's own (c / rho_s) D^-1.  A subdomain's
+// hierarchy then does not depend on which other subdomains share the batch: the same V-cycle whether the rank holds
+// eight subdomains or one (bench.py --scaling strong: N = 1, 2, 4, 8), or the eigensolves run group by group
+// (PC::eigen_grouped).  Blocks that attain the maximum (every block of the fine-level Laplacian) are scaled by exactly 1.
+static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv, const std::vector<int>& suboff) {
   dinv.assign(a.n, 1.0);
-  std::vector<double> part(64, 0.0);
-  std::vector<char> bad(64, 0);
-  int slot = 0;
+  const int nsub = std::max(1, (int)suboff.size() - 1);
+  std::vector<double> rho_s(nsub, 0.0);
+  bool bad = false;
   std::mutex mu;
   parallel_rows(a.n, [&](int r0, int r1) {
-    double rho = 0.0;
     bool neg = false;
+    int sd = suboff.size() > 1 ? (int)(std::upper_bound(suboff.begin(), suboff.end(), r0) - suboff.begin()) - 1 : 0;
+    std::vector<std::pair<int, double>> mine;      // (subdomain, bound over this range's rows of it)
+    double rho = 0.0;
     for (int i = r0; i < r1; ++i) {
+      if (suboff.size() > 1 && i >= suboff[sd + 1]) {
+        mine.emplace_back(sd, rho);
+        rho = 0.0;
+        while (i >= suboff[sd + 1]) ++sd;
+      }
       double d = 0.0, row = 0.0;
       for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
         row += std::fabs(a.val[k]);
@@ -344,17 +358,25 @@ static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv) {
       dinv[i] = 1.0 / d;
       rho = std::max(rho, row / d);
     }
+    if (r1 > r0) mine.emplace_back(sd, rho);
     std::lock_guard<std::mutex> lk(mu);
-    part[slot] = rho;
-    bad[slot] = neg;
-    ++slot;
+    for (auto& kv : mine) rho_s[std::min(kv.first, nsub - 1)] = std::max(rho_s[std::min(kv.first, nsub - 1)], kv.second);
+    bad = bad || neg;
   });
+  if (bad) throw std::runtime_error("AMG: non-positive diagonal");
   double rho = 0.0;
-  for (int t = 0; t < slot; ++t) {
-    if (bad[t]) throw std::runtime_error("AMG: non-positive diagonal");
-    rho = std::max(rho, part[t]);
+  for (double v : rho_s) rho = std::max(rho, v);
+  if (!(rho > 0)) return 2.0;
+  if (suboff.size() > 2) {
+    for (int s = 0; s < nsub; ++s) {
+      if (!(rho_s[s] > 0.0) || rho_s[s] == rho) continue;
+      const double f = rho / rho_s[s];
+      parallel_rows(suboff[s + 1] - suboff[s], [&](int r0, int r1) {
+        for (int i = suboff[s] + r0; i < suboff[s] + r1; ++i) dinv[i] *= f;
+      });
+    }
   }
-  return rho > 0 ? rho : 2.0;
+  return rho;
 }
 
 // dense inverse of every coarsest block (SPD: Cholesky; tiny pivots regularised)
@@ -381,7 +403,17 @@ static void coarse_inverse(const HostCsr& CA, const std::vector<int>& csuboff, s
     // pinned, the V-cycle then applies a bounded generalised inverse instead of amplifying the kernel component of
     // every residual by 1 / rounding.
     std::vector<double> l = a;
-    const int fixed = dense::cholesky_fix_null_pivots(l, m);
+    int fixed = dense::cholesky_fix_null_pivots(l, m);
+    if (fixed < 0) {
+      // A Galerkin block that is positive semi-definite by construction may come out indefinite by a rounding error
+      // larger than the null-pivot window: one retry with a trace shift of 1e-10 (a preconditioner's coarsest solve:
+      // the outer PCG absorbs it) before the block is declared indefinite.
+      double tr = 0.0;
+      for (int i = 0; i < m; ++i) tr += std::fabs(a[(size_t)i * m + i]);
+      l = a;
+      for (int i = 0; i < m; ++i) l[(size_t)i * m + i] += 1e-10 * tr / m;
+      fixed = dense::cholesky_fix_null_pivots(l, m);
+    }
     if (fixed < 0) throw std::runtime_error("AMG: coarsest block is not positive semi-definite");
     if (fixed > 0) g_null_pivots.fetch_add(fixed);
     std::vector<double> e(m);
@@ -396,11 +428,19 @@ static void coarse_inverse(const HostCsr& CA, const std::vector<int>& csuboff, s
   {
     const int nth = std::max(1, std::min(nsub, std::min(16, (int)std::thread::hardware_concurrency())));
     std::vector<std::thread> th;
+    std::exception_ptr err;      // an indefinite block must come back as an error of the set-up, not std::terminate
+    std::mutex emu;
     for (int t = 0; t < nth; ++t)
       th.emplace_back([&, t]() {
-        for (int s = t; s < nsub; s += nth) invert(s);
+        try {
+          for (int s = t; s < nsub; s += nth) invert(s);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(emu);
+          if (!err) err = std::current_exception();
+        }
       });
     for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
   }
 }
 
@@ -416,7 +456,7 @@ void amg_setup_host(const HostCsr& A, const std::vector<int>& suboff, const AmgP
   while (true) {
     AmgLevelHost& L = levels.back();
     const HostCsr& LA = (levels.size() == 1) ? A : L.A;   // level 0: the caller's matrix, not a copy
-    L.rho = gershgorin_rho(LA, L.dinv);
+    L.rho = gershgorin_rho(LA, L.dinv, L.suboff);
     int maxblk = 0;
     for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, L.suboff[s + 1] - L.suboff[s]);
     if (maxblk <= prm.coarse_size || (int)levels.size() >= prm.max_levels) break;
@@ -651,7 +691,7 @@ AmgLevelHostPart amg_level_host_part(const HostCsr& Ah, const std::vector<int>& 
   AmgLevelHostPart h;
   const int nsub = (int)so.size() - 1;
   const auto t_hp0 = std::chrono::high_resolution_clock::now();
-  h.rho = gershgorin_rho(Ah, h.dinv);
+  h.rho = gershgorin_rho(Ah, h.dinv, so);
   const auto t_hp1 = std::chrono::high_resolution_clock::now();
   int maxblk = 0;
   for (int s = 0; s < nsub; ++s) maxblk = std::max(maxblk, so[s + 1] - so[s]);

@@ -36,6 +36,10 @@ int   thread_device_check();             // test hook: device of a freshly start
 void* alloc(size_t bytes);                // HBM allocation (zero-initialised)
 void  dfree(void* p);
 void  alloc_cache_release();   // hipFree every block the caching allocator holds (backend_hip.hip: alloc)
+// bytes: handed out now / their high-water mark / high-water mark of handed out + parked in the cache / parked now /
+// hipMemGetInfo free and total; reset_peaks restarts both high-water marks at the current state (any pointer may be null)
+void  mem_info(double* live, double* live_peak, double* footprint_peak, double* cached, double* dev_free, double* dev_total,
+               bool reset_peaks);
 void  alloc_stats(double* alloc_s, double* free_s, long long* n);   // time spent in hipMalloc / hipFree since the last call
 void  h2d(void* d, const void* h, size_t bytes);
 void  d2h(void* h, const void* d, size_t bytes);   // synchronous w.r.t. the stream
@@ -273,6 +277,11 @@ void zt_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int*
 // wL[i] (+)= sum_j Z_s[j][i] * yE[zoff[s]+j]
 void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* ksub, const int* zoff,
              const double* yE, double* wL, bool accumulate);
+
+// y <- (L L^T)^-1 y for a dense Cholesky factor held twice (L and L^T, n x n row-major, device): the replicated coarse
+// solve, in place and stream-ordered.  Same arithmetic order as dense::cholesky_solve_lu.  false: n beyond the kernel's
+// capacity (1024), nothing done -- the caller takes the host path.
+bool chol_solve(const double* L, const double* LT, int n, double* y);
 
 // ---- HIP graphs -------------------------------------------------------------------------------
 // Launch-bound inner loops (one inner PCG chunk = ~70 small kernels) are captured once and replayed.

@@ -171,6 +171,14 @@ struct Parked { void* p; hipStream_t stream; hipEvent_t ev; };
 static std::multimap<size_t, Parked> g_cache;
 static std::vector<hipEvent_t> g_ev_pool;
 static size_t g_cache_bytes = 0;
+// device-memory accounting of the library's own blocks (bench.py's device_mem_peak_gb): bytes handed out, their
+// high-water mark, and the high-water mark of handed out + parked (what the process holds of the card)
+static size_t g_live_bytes = 0, g_live_peak = 0, g_foot_peak = 0;
+static inline void mem_account(long long delta_live) {      // caller holds g_alloc_mu
+  g_live_bytes = (size_t)((long long)g_live_bytes + delta_live);
+  g_live_peak = std::max(g_live_peak, g_live_bytes);
+  g_foot_peak = std::max(g_foot_peak, g_live_bytes + g_cache_bytes);
+}
 static bool alloc_cache_on() {
   static const bool on = !(getenv("GENEO_ALLOC_CACHE") && !strcmp(getenv("GENEO_ALLOC_CACHE"), "0"));
   return on;
@@ -214,6 +222,7 @@ void* alloc(size_t bytes) {
       }
       g_live[p] = it->first;
       g_cache_bytes -= it->first;
+      mem_account((long long)it->first);
       g_cache.erase(it);
     }
   }
@@ -232,7 +241,8 @@ void* alloc(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_alloc_s += dt;
     ++g_alloc_n;
-    if (alloc_cache_on()) g_live[p] = sz;
+    g_live[p] = sz;
+    mem_account((long long)sz);
   }
   HIPCHK(hipMemsetAsync(p, 0, bytes, g_stream));
   return p;
@@ -240,13 +250,14 @@ void* alloc(size_t bytes) {
 void dfree(void* p) {
   if (!p) return;
   bind_thread();
-  if (alloc_cache_on()) {
+  {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     auto it = g_live.find(p);
     if (it != g_live.end()) {
       const size_t sz = it->second;
       g_live.erase(it);
-      if (g_cache_bytes + sz <= alloc_cache_cap()) {
+      mem_account(-(long long)sz);
+      if (alloc_cache_on() && g_cache_bytes + sz <= alloc_cache_cap()) {
         Parked pk{p, g_stream, nullptr};
         if (!g_capturing) {
           if (!g_ev_pool.empty()) { pk.ev = g_ev_pool.back(); g_ev_pool.pop_back(); }
@@ -262,6 +273,23 @@ void dfree(void* p) {
   auto t0 = std::chrono::high_resolution_clock::now();
   (void)hipFree(p);
   g_free_s += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+}
+void mem_info(double* live, double* live_peak, double* footprint_peak, double* cached, double* dev_free, double* dev_total,
+              bool reset_peaks) {
+  bind_thread();
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); f = t = 0; }
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  if (live) *live = (double)g_live_bytes;
+  if (live_peak) *live_peak = (double)g_live_peak;
+  if (footprint_peak) *footprint_peak = (double)g_foot_peak;
+  if (cached) *cached = (double)g_cache_bytes;
+  if (dev_free) *dev_free = (double)f;
+  if (dev_total) *dev_total = (double)t;
+  if (reset_peaks) {
+    g_live_peak = g_live_bytes;
+    g_foot_peak = g_live_bytes + g_cache_bytes;
+  }
 }
 void alloc_stats(double* alloc_s, double* free_s, long long* n) {
   *alloc_s = g_alloc_s; *free_s = g_free_s; *n = g_alloc_n;
@@ -4695,6 +4723,65 @@ void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, co
   if (c.nchunk == 0) return;
   hipLaunchKernelGGL(k_dense_sym_apply, dim3(c.nchunk), dim3(256), 0, g_stream, c.start, c.len, c.sub, c.suboff, inv,
                      base, B, ldb, X, ldx, m);
+}
+
+// =============================================================================== replicated coarse solve
+// x = (L L^T)^-1 b for the replicated coarse operator E (dimE <= 1024), ONE workgroup, in place on the device: the two
+// triangular sweeps of applyQ's coarse solve (geneo.cpp:1474-1513: KSPSolve(pcKSPL2)) stream-ordered behind the all-reduce
+// of Z^T x instead of a download, two host sweeps and an upload.  Thread t owns unknown t in a
+// register.  Column-oriented sweeps: step k publishes x_k through LDS (one barrier) and every later unknown subtracts
+// L_tk x_k -- for unknown t the subtractions come in the order k = 0, 1, .. (forward) and k = n - 1, n - 2, .. (backward),
+// exactly dense::cholesky_solve_lu's, so host and device produce the same bits.  The matrix entries of PB steps are
+// loaded together (PB loads in flight per thread: column k of L is row k of L^T and vice versa, contiguous in t).
+template <int PB>
+__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ L, const double* __restrict__ LT, int n,
+                                                     double* __restrict__ y) {
+  extern __shared__ double xs[];   // n published unknowns
+  const int t = threadIdx.x;
+  double yv = (t < n) ? y[t] : 0.0;
+  const double dg = (t < n) ? L[(int64_t)t * n + t] : 1.0;
+  for (int k0 = 0; k0 < n; k0 += PB) {                 // L z = b
+    double c[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int k = k0 + p;
+      c[p] = (k < n && t > k && t < n) ? LT[(int64_t)k * n + t] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int k = k0 + p;
+      if (k < n) {                                     // (uniform)
+        if (t == k) { yv = yv / dg; xs[k] = yv; }
+        __syncthreads();
+        if (t > k) yv -= c[p] * xs[k];
+      }
+    }
+  }
+  for (int k0 = 0; k0 < n; k0 += PB) {                 // L^T x = z, from the last unknown down
+    double c[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int k = n - 1 - (k0 + p);
+      c[p] = (k >= 0 && t < k) ? L[(int64_t)k * n + t] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int k = n - 1 - (k0 + p);
+      if (k >= 0) {
+        if (t == k) { yv = yv / dg; xs[k] = yv; }
+        __syncthreads();
+        if (t < k) yv -= c[p] * xs[k];
+      }
+    }
+  }
+  if (t < n) y[t] = yv;
+}
+bool chol_solve(const double* L, const double* LT, int n, double* y) {
+  if (n <= 0) return true;
+  if (n > 1024) return false;
+  const int threads = ((n + 63) / 64) * 64;
+  hipLaunchKernelGGL((k_chol_solve<16>), dim3(1), dim3(threads), sizeof(double) * n, g_stream, L, LT, n, y);
+  return true;
 }
 
 // =============================================================================== self test / events

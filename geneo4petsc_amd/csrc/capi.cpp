@@ -155,6 +155,10 @@ const char* usageGenEO_c(void) {
          "                     - check partition of unity\n"
          "                     - check matrices are SPD (check.SPD.A.log, check<id>.SPD.<pb>.B.log)\n"
          "                     - check R from Z=QR (check<id>.setup.Z.R, check.setup.ZE2G.R)\n"
+         "  -geneo_nicolaides_zero X   the Nicolaides rule takes min(lambda) >= X eps as 'no zero eigenvalue found'\n"
+         "                   (1 = the reference's literal test; defaults to 100)\n"
+         "  -geneo_eig_group_rows R / -geneo_eig_mem_gb G   memory-bounded set-up: eigensolve the rank's subdomains in\n"
+         "                   consecutive groups of at most R local rows / G GiB of basis blocks (default: 35 % of the card)\n"
          "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_pc_type amg|cheb\n"
          "  -els2_cheb_degree / -els2_cheb_ratio\n"
          "  -dls1_ksp_rtol / -dls1_ksp_max_it / -dls1_pc_type amg|jacobi   local solves (batched PCG)\n"
@@ -348,6 +352,7 @@ PetscErrorCode PCGenEOGetInfo(PC pc, GeneoInfo* o) {
   o->lvl2ApplyZTimeLoc = i.lvl2ApplyZTimeLoc; o->setupTime = i.setupTime; o->solveTime = i.solveTime;
   o->amg_levels = i.amg_levels; o->amg_operator_complexity = i.amg_operator_complexity; o->amgSetupTime = i.amgSetupTime;
   o->nullPivotsLoc = i.nullPivotsLoc;
+  o->eigGroups = i.eig_groups;
   return 0;
 }
 static int copy_out(const std::vector<double>& v, double* out, int cap) {
@@ -550,6 +555,13 @@ PetscErrorCode GeneoSpmvProfileStart(int every, double min_bytes) {
 PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long* nsampled, long long* nlaunch) {
   GUARD_BEGIN
   bk::spmv_profile_stop(ms_sum, bytes_sum, nsampled, nlaunch);
+  GUARD_END((PC) nullptr)
+  return 0;
+}
+PetscErrorCode GeneoDeviceMemInfo(double* live, double* live_peak, double* footprint_peak, double* cached, double* dev_free,
+                                  double* dev_total, int reset_peaks) {
+  GUARD_BEGIN
+  bk::mem_info(live, live_peak, footprint_peak, cached, dev_free, dev_total, reset_peaks != 0);
   GUARD_END((PC) nullptr)
   return 0;
 }

@@ -137,6 +137,14 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   if (key == "-els2_cheb_degree") return integer(o.cheb_degree);
   if (key == "-els2_cheb_ratio") return dbl(o.cheb_ratio);
   if (key == "-els2_rr_drop") return dbl(o.rr_drop);
+  if (key == "-geneo_nicolaides_zero") {
+    double v;
+    if (!to_double(value, v) || !(v >= 0.0)) return "invalid option -geneo_nicolaides_zero, bad " + value;
+    o.nicolaides_zero = v;
+    return "";
+  }
+  if (key == "-geneo_eig_group_rows") return integer(o.eig_group_rows);
+  if (key == "-geneo_eig_mem_gb") return dbl(o.eig_mem_gb);
   if (key == "-els2_eps_seed") { int v; if (!to_int(value, v)) return "bad seed"; o.eps_seed = (uint64_t)v; return ""; }
   if (key == "-dls1_ksp_rtol") return dbl(o.dls1_rtol);
   if (key == "-dls1_ksp_max_it") return integer(o.dls1_max_it);
@@ -216,9 +224,9 @@ static std::string check_id(int gid, int nsub);
 // (--inpEps 0) the computed zero eigenvalue is a rounding error of either sign and any size around 1e-16 -- LAPACK returns
 // +2e-15 on two of the four floating subdomains of a 20^3 grid, LOBPCG on the GPU +4e-16 on one --, and whenever it lands
 // above DBL_EPSILON the reference's test adds the kernel vector a SECOND time: a rank-deficient Z and a singular E.
-// An eigenvalue below 100 DBL_EPSILON is therefore taken as the zero it is; outside that window (every case the
-// reference's own tests exercise) the rule is the reference's.
-static const double NICOLAIDES_ZERO = 100.0 * DBL_EPSILON;
+// An eigenvalue below 100 DBL_EPSILON is therefore taken as the zero it is by default; outside that window (every case
+// the reference's own tests exercise) the rule is the reference's.  -geneo_nicolaides_zero <x> sets the window to
+// x DBL_EPSILON: 1 is the reference's literal test (geneo.cpp:898-899).
 
 int PC::fail(const std::string& msg) {
   last_error = msg;
@@ -242,12 +250,12 @@ void PC::free_all() {
   if (ch.start) bk::chunks_free(ch);
   void* ptrs[] = {d_l2e, d_rt_ptr, d_rt_idx, d_send_idx, d_rv_ptr, d_rv_idx, d_rv_tgt, d_D, d_dinv1, d_dinvN, d_xe,
                   d_ye, d_xL, d_wL, d_cg_r, d_cg_z, d_cg_p, d_cg_q, d_cg_sc, d_t1, d_t2, d_t3, d_x0, d_scal,
-                  d_rvtmp, d_Z, d_zbase, d_ksub, d_zoff, d_subgid, d_yE};
+                  d_rvtmp, d_Z, d_zbase, d_ksub, d_zoff, d_subgid, d_yE, d_EL, d_ELT};
   for (void* p : ptrs) bk::dfree(p);
   d_l2e = d_rt_ptr = d_rt_idx = d_send_idx = d_rv_ptr = d_rv_idx = d_rv_tgt = nullptr;
   d_D = d_dinv1 = d_dinvN = d_xe = d_ye = d_xL = d_wL = nullptr;
   d_cg_r = d_cg_z = d_cg_p = d_cg_q = d_cg_sc = d_t1 = d_t2 = d_t3 = d_x0 = d_scal = d_rvtmp = nullptr;
-  d_Z = nullptr; d_zbase = nullptr; d_ksub = d_zoff = d_subgid = nullptr; d_yE = nullptr;
+  d_Z = nullptr; d_zbase = nullptr; d_ksub = d_zoff = d_subgid = nullptr; d_yE = nullptr; d_EL = d_ELT = nullptr;
   is_setup = false;
 }
 
@@ -682,8 +690,13 @@ int PC::setup(const double* b_dev) {
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } dir_joiner{dir_thread};
   if (!single_block) make_blockdiag(neu, suboff, nullptr, h_neuL_own);
   const HostCsr& h_neuL = single_block ? *neu[0] : h_neuL_own;
-  const bool want1 = (opt.dls1_pc == "amg");
-  const bool wantN = (opt.lvl2 && opt.els2_pc == "amg");
+  // memory-bounded set-up: the eigensolve of this rank's subdomains in consecutive groups (eigen_grouped), each with its
+  // own A_Neu hierarchy -- this PC then builds none
+  eig_groups = plan_eig_groups();
+  const bool grouped = eig_groups.size() > 2;
+  info.eig_groups = (int)eig_groups.size() - 1;
+  const bool want1 = (opt.dls1_pc == "amg") && !eig_only;
+  const bool wantN = (opt.lvl2 && opt.els2_pc == "amg") && !grouped;
   const AmgParams ap = amg_params(opt);
   AmgParams ap1h = ap;                      // the level-1 hierarchy (local solves): its own aggregation strength
   ap1h.strength = opt.dls1_amg_strength;
@@ -709,7 +722,7 @@ int PC::setup(const double* b_dev) {
   lap("upload A_Neu");
   // same matrix with ext-space columns (l2e o col) for the MATIS MatMult, so that the gather R x is fused into the
   // SpMV; own copy (the sliced layout embeds the columns), made on the device from the one just uploaded
-  neuE = bk::csr_remap_columns(neuL, d_l2e);
+  if (!eig_only) neuE = bk::csr_remap_columns(neuL, d_l2e);
   lap("ext-space copy");
   dir_thread.join();
   if (dir_err) {
@@ -722,8 +735,14 @@ int PC::setup(const double* b_dev) {
   lap("A_Dir blockdiag (joined)");
   pend1.reset(want1 ? new Amg1Pending() : nullptr);
   if (want1) {
-    if (single_block) pend1->matp = lvl1[0];        // subs[0].a_dir or the Robin matrix of this set-up: both outlive the thread
-    else {
+    if (single_block && opt.lvl1ORAS) {
+      // the Robin matrix is a local of this function: the hierarchy thread reads it until it is joined (finish_amg1, or
+      // ~Amg1Pending on an error path), so it moves into the pending object and lives exactly as long as the thread
+      pend1->mat_own = std::move(rob[0]);
+      pend1->matp = lvl1[0] = &pend1->mat_own;
+    } else if (single_block) {
+      pend1->matp = lvl1[0];                       // subs[0].a_dir: a member of this PC, outlives the thread
+    } else {
       pend1->matp = &h_dirL_own;                   // the PC's own copy: outlives the thread
     }
     if (early0 && !getenv("GENEO_AMG1_HOST")) {
@@ -1115,11 +1134,16 @@ void PC::coarse_solve_local(const double* xL, double* yE) {
   auto t0 = clk::now();
   bk::zt_apply(ch, d_Z, d_zbase, d_ksub, d_zoff, kmax, xL, yE, dimE);
   allreduce(yE, dimE);
-  bk::d2h(h_yE.data(), yE, sizeof(double) * dimE);
   auto t1 = clk::now();
-  if (E_chol) dense::cholesky_solve_lu(Efac, EfacT, dimE, h_yE.data());
-  else dense::lu_solve(Efac, dimE, Epiv, h_yE.data());
-  bk::h2d(yE, h_yE.data(), sizeof(double) * dimE);
+  // E^-1 (geneo.cpp:1493, KSPSolve(pcKSPL2)): the replicated Cholesky factor lives on the device and the two triangular
+  // sweeps are one launch behind the all-reduce -- no download, host solve, upload and no host synchronisation in the
+  // preconditioner application.  Host path: E not positive definite to rounding (LU with pivoting) or dimE > 1024.
+  if (!(E_chol && d_EL && bk::chol_solve(d_EL, d_ELT, dimE, yE))) {
+    bk::d2h(h_yE.data(), yE, sizeof(double) * dimE);
+    if (E_chol) dense::cholesky_solve_lu(Efac, EfacT, dimE, h_yE.data());
+    else dense::lu_solve(Efac, dimE, Epiv, h_yE.data());
+    bk::h2d(yE, h_yE.data(), sizeof(double) * dimE);
+  }
   auto t2 = clk::now();
   info.lvl2ApplyZtTimeLoc += secs(t0, t1);
   info.lvl2ApplyEinvTimeLoc += secs(t1, t2);
@@ -1203,6 +1227,7 @@ int PC::setup_level2(const double* b_dev) {
   int rc = 0;
   try {
     if (nmax <= 192) rc = eigen_dense_host();
+    else if (eig_groups.size() > 2) rc = eigen_grouped();
     else rc = eigen_lobpcg();
   } catch (std::exception& e) {
     return fail(e.what());
@@ -1211,6 +1236,7 @@ int PC::setup_level2(const double* b_dev) {
   bk::sync();
   auto t1 = clk::now();
   info.lvl2SetupEigTimeLoc = secs(t0, t1);
+  if (eig_only) return 0;      // a group of eigen_grouped: Z, the eigenvalues and the counters are what the owner takes
   if (int r1 = finish_amg1()) return r1;
   t1 = clk::now();
   try {
@@ -1315,7 +1341,7 @@ int PC::eigen_dense_host() {
       vecs[s].push_back(std::move(v));
     }
     // Nicolaides (geneo.cpp:897-944)
-    if (!eigvals[s].empty() && *std::min_element(eigvals[s].begin(), eigvals[s].end()) >= NICOLAIDES_ZERO) {
+    if (!eigvals[s].empty() && *std::min_element(eigvals[s].begin(), eigvals[s].end()) >= opt.nicolaides_zero * DBL_EPSILON) {
       double num = 0.0, den = 0.0;
       for (size_t e = 0; e < GA.size(); ++e) { num += GA[e]; den += GB[e]; }
       if (std::fabs(num / den) <= FLT_EPSILON) {
@@ -1383,16 +1409,14 @@ class HostPool {
       for (int s = s0; s < s1; ++s) f(s);
       return;
     }
-    // one work list at a time: a second PC setting up on another host thread waits here; a nested run() from inside a
-    // work item runs its items inline (the pool is busy with the outer list)
-    std::unique_lock<std::mutex> one(run_mu, std::try_to_lock);
-    if (!one.owns_lock()) {
-      if (in_pool_work) {
-        for (int s = s0; s < s1; ++s) f(s);
-        return;
-      }
-      one.lock();
+    // a nested run() from inside a work item runs its items inline: the pool is busy with the outer list, and the thread
+    // that owns run_mu (the outer caller, working through its share) must not try to lock it a second time
+    if (in_pool_work) {
+      for (int s = s0; s < s1; ++s) f(s);
+      return;
     }
+    // one work list at a time: a second PC setting up on another host thread waits here
+    std::unique_lock<std::mutex> one(run_mu);
     std::exception_ptr err;
     {
       std::unique_lock<std::mutex> lk(mu);
@@ -2274,9 +2298,11 @@ int PC::eigen_lobpcg() {
         any = true;
         for (int j = 0; j < nv; ++j) cs[(size_t)s * cur.m + j] = 1.0;
         locked_cols[s] += nv;
-        if (locked_cols[s] + 48 > 256)
+        if (locked_cols[s] + 48 > 256) {
+          out.push_back(cur);      // the stage's vectors belong to `out` from here on: release_all() frees them
           return fail("GenEO: more than 256 eigenvalues pass the threshold in one subdomain (coarse-space kernels hold 256 "
                       "vectors per subdomain): set -geneo_cut or lower -geneo_tau");
+        }
       }
       out.push_back(cur);
       if (!any) return 0;
@@ -2284,13 +2310,14 @@ int PC::eigen_lobpcg() {
       double* BY = dv((size_t)nL * cur.m);
       lock_bufs.push_back(Y);
       lock_bufs.push_back(BY);
-      double* dcs = dv(cs.size());
-      bk::h2d(dcs, cs.data(), sizeof(double) * cs.size());
-      bk::block_axpby(Y, cur.m, 1.0, cur.X, cur.m, 0.0, nL, cur.m);
-      bk::block_colscale(ch, Y, cur.m, cur.m, dcs);
-      bk::spmm_strided(*P.B, Y, cur.m, BY, cur.m, cur.m, P.Bs, P.Bs);
-      bk::sync();
-      bk::dfree(dcs);
+      {
+        struct DevBuf { double* p; ~DevBuf() { bk::dfree(p); } } dcs{dv(cs.size())};   // released on a throwing launch too
+        bk::h2d(dcs.p, cs.data(), sizeof(double) * cs.size());
+        bk::block_axpby(Y, cur.m, 1.0, cur.X, cur.m, 0.0, nL, cur.m);
+        bk::block_colscale(ch, Y, cur.m, cur.m, dcs.p);
+        bk::spmm_strided(*P.B, Y, cur.m, BY, cur.m, cur.m, P.Bs, P.Bs);
+        bk::sync();
+      }
       locked_blocks.push_back({Y, BY, cur.m});
       Stage nxt;
       nxt.m = 64;
@@ -2388,7 +2415,7 @@ int PC::eigen_lobpcg() {
         minval = std::min(minval, l);
       }
     }
-    if (cnt > 0 && minval >= NICOLAIDES_ZERO) {
+    if (cnt > 0 && minval >= opt.nicolaides_zero * DBL_EPSILON) {
       const double ratio = std::fabs(sc[(size_t)s * 8 + 0] / sc[(size_t)s * 8 + 1]);
       if (ratio <= FLT_EPSILON) {
         const size_t g = stT.size() - 1;      // appended behind every eigenvector, as the reference does (:897-944)
@@ -2461,6 +2488,151 @@ int PC::eigen_lobpcg() {
   bk::dfree(dsel);
   bk::dfree(dks);
   release_all();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ memory-bounded set-up
+// Which consecutive subdomains are eigensolved together ({0, ns}: all at once, the plain path).  GenEO-1 without
+// -geneo_chk only: GenEO-2's gamma problem runs through the level-1 hierarchy and needs the other subdomains' flags.
+std::vector<int> PC::plan_eig_groups() const {
+  const int ns = (int)subs.size();
+  const std::vector<int> all = {0, ns};
+  if (eig_only || ns < 2 || opt.lvl2 != 1 || opt.check) return all;
+  int nmax = 0;
+  for (auto& s : subs) nmax = std::max(nmax, (int)s.l2g.size());
+  if (nmax <= 192) return all;
+  const int m = eig_block_max();
+  int64_t cap = opt.eig_group_rows;
+  if (cap <= 0) {
+    double budget = opt.eig_mem_gb * 1073741824.0;
+    if (budget <= 0.0) {
+      double total = 0.0;
+      bk::mem_info(nullptr, nullptr, nullptr, nullptr, nullptr, &total, false);
+      if (total <= 0.0) return all;
+      budget = 0.35 * total;
+    }
+    // six n x 3m basis blocks when the iteration starts, three n x m residual / direction blocks, the V-cycle's block
+    // work space (~4 m per fine row over all levels), the Ritz vectors, the hierarchy and the fine matrices themselves
+    const double per_row = 8.0 * 30.0 * m + 700.0;
+    cap = (int64_t)(budget / per_row);
+  }
+  cap = std::max<int64_t>(1, std::min<int64_t>(cap, (int64_t)0x7fffffff / (3 * m) - 1));   // n x 3m blocks: 32-bit element indices
+  // the fewest groups the cap allows (greedy), then the same number of groups with the rows spread evenly: equal
+  // subdomains give equal groups, whose device blocks the caching allocator hands from one group to the next
+  auto split = [&](int64_t lim) {
+    std::vector<int> gb = {0};
+    int64_t rows = 0;
+    for (int s = 0; s < ns; ++s) {
+      const int64_t n = (int64_t)subs[s].l2g.size();
+      if (rows > 0 && rows + n > lim) {
+        gb.push_back(s);
+        rows = 0;
+      }
+      rows += n;
+    }
+    gb.push_back(ns);
+    return gb;
+  };
+  std::vector<int> gb = split(cap);
+  const int ng = (int)gb.size() - 1;
+  if (ng > 1) {
+    int64_t total = 0, nmax64 = 0;
+    for (auto& s : subs) { total += (int64_t)s.l2g.size(); nmax64 = std::max<int64_t>(nmax64, (int64_t)s.l2g.size()); }
+    for (int64_t lim = std::max(nmax64, (total + ng - 1) / ng); lim <= cap; lim += std::max<int64_t>(1, nmax64 / 8)) {
+      std::vector<int> even = split(lim);
+      if ((int)even.size() - 1 == ng) { gb = even; break; }
+    }
+  }
+  return gb;
+}
+
+// The eigensolve of this rank's subdomains group by group.  Each group is handed to a temporary PC (eig_only) as a
+// problem of its own -- its subdomains in local numbering, their matrices MOVED in and back, never copied --, which runs
+// the ordinary set-up up to the end of eigen_lobpcg and is destroyed before the next group starts: its fine matrices, its
+// A_Neu hierarchy and the LOBPCG blocks are all that ever coexist with this PC's resident matrices.  A subdomain's
+// iteration depends on nothing outside its own rows (start block from its global id and local row, per-subdomain
+// Rayleigh-Ritz, per-subdomain freezing), so eigenvalues, kept counts and Z are those of the all-at-once path.
+int PC::eigen_grouped() {
+  const int ns = (int)subs.size();
+  const int ng = (int)eig_groups.size() - 1;
+  ksub.assign(ns, 0);
+  info.eig_iterations = 0;
+  std::vector<double*> zpiece(ng, nullptr);
+  auto drop_pieces = [&]() {
+    for (double* p : zpiece) bk::dfree(p);
+  };
+  for (int g = 0; g < ng; ++g) {
+    const int s0 = eig_groups[g], s1 = eig_groups[g + 1];
+    PC q;
+    q.opt = opt;
+    q.eig_only = true;
+    q.nsub_global = nsub_global;
+    q.N = suboff[s1] - suboff[s0];
+    q.subs.resize(s1 - s0);
+    auto move_subs = [&](bool back) {
+      for (int s = s0; s < s1; ++s) {
+        Sub &a = subs[s], &b = q.subs[s - s0];
+        std::swap(a.mult, b.mult);
+        std::swap(a.a_neu, b.a_neu);
+        std::swap(a.a_dir, b.a_dir);
+        if (!back) {
+          b.gid = a.gid;
+          b.l2g.resize(a.l2g.size());
+          std::iota(b.l2g.begin(), b.l2g.end(), suboff[s] - suboff[s0]);
+        }
+      }
+    };
+    move_subs(false);
+    int rc = 1;
+    std::string err;
+    try {
+      rc = q.setup(nullptr);
+      if (rc) err = q.last_error;
+    } catch (std::exception& e) {
+      err = e.what();
+    }
+    move_subs(true);
+    if (rc) {
+      drop_pieces();
+      return fail(err.empty() ? "GenEO: grouped eigensolve failed" : err);
+    }
+    for (int s = s0; s < s1; ++s) {
+      eigvals[s] = q.eigvals[s - s0];
+      candidates[s] = q.candidates[s - s0];
+      ksub[s] = q.ksub[s - s0];
+    }
+    info.nicolaidesLoc += q.info.nicolaidesLoc;
+    info.estimDimELoc += q.info.estimDimELoc;
+    info.eig_iterations = std::max(info.eig_iterations, q.info.eig_iterations);   // as in one batch: the slowest subdomain's
+    info.eig_spmm += q.info.eig_spmm;
+    info.amgSetupTime += q.info.amgSetupTime;
+    if (g == 0) {
+      info.amg_on_device = q.info.amg_on_device;
+      if (!amg1 && !pend1) {
+        info.amg_levels = q.info.amg_levels;
+        info.amg_operator_complexity = q.info.amg_operator_complexity;
+      }
+    }
+    zpiece[g] = q.d_Z;            // column-major Z_s of the group's subdomains, back to back
+    q.d_Z = nullptr;
+    if (getenv("GENEO_DEBUG"))
+      fprintf(stderr, "[setup] eigensolve group %d of %d: subdomains %d..%d, %d rows, %d LOBPCG iterations, set-up of the group %.3f s\n",
+              g + 1, ng, s0, s1 - 1, q.N, q.info.eig_iterations, q.info.setupTime);
+  }
+  std::vector<int64_t> zbase(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) {
+    if (ksub[s] > 256) { drop_pieces(); return fail("GenEO: more than 256 coarse vectors in one subdomain: set -geneo_cut or lower -geneo_tau"); }
+    zbase[s + 1] = zbase[s] + (int64_t)ksub[s] * (int64_t)subs[s].l2g.size();
+  }
+  d_Z = (double*)bk::alloc(sizeof(double) * (size_t)std::max<int64_t>(1, zbase[ns]));
+  d_zbase = (int64_t*)bk::alloc(sizeof(int64_t) * (ns + 1));
+  bk::h2d(d_zbase, zbase.data(), sizeof(int64_t) * (ns + 1));
+  for (int g = 0; g < ng; ++g) {
+    const int64_t b0 = zbase[eig_groups[g]], b1 = zbase[eig_groups[g + 1]];
+    if (b1 > b0) bk::d2d(d_Z + b0, zpiece[g], sizeof(double) * (size_t)(b1 - b0));
+  }
+  bk::sync();
+  drop_pieces();
   return 0;
 }
 
@@ -2816,6 +2988,12 @@ int PC::build_E() {
     EfacT.assign(Efac.size(), 0.0);
     for (int a = 0; a < dimE; ++a)
       for (int b = 0; b <= a; ++b) EfacT[(size_t)b * dimE + a] = Efac[(size_t)a * dimE + b];
+  }
+  if (E_chol && dimE > 0 && dimE <= 1024) {     // the factor, twice, for the device sweeps of coarse_solve_local
+    d_EL = (double*)bk::alloc(sizeof(double) * Efac.size());
+    d_ELT = (double*)bk::alloc(sizeof(double) * EfacT.size());
+    bk::h2d(d_EL, Efac.data(), sizeof(double) * Efac.size());
+    bk::h2d(d_ELT, EfacT.data(), sizeof(double) * EfacT.size());
   }
   if (!E_chol) {
     Efac = sym;

@@ -29,6 +29,10 @@ struct Options {
   int cut = -1;
   bool noSyl = false, offload = false;
   bool check = false;      // -geneo_chk (geneo.cpp:2466-2479)
+  // -geneo_nicolaides_zero <x>: the Nicolaides rule (geneo.cpp:896-944) takes min(lambda) >= x DBL_EPSILON as "zero has
+  // not been found".  1 = the reference's literal test; default 100 (a computed zero eigenvalue of an exactly singular
+  // Neumann matrix is a rounding error of either sign around 1e-16 .. 2e-15: core.cpp)
+  double nicolaides_zero = 100.0;
   // -els2_ : local eigensolver (LOBPCG on the GPU replaces ARPACK shift-invert, geneo.cpp:626-744)
   double eps_tol = 1e-3;   // EPSSetTolerances default at geneo.cpp:658
   int eps_nev = 16;        // block target when -geneo_cut is not given (no inertia count on the GPU)
@@ -39,6 +43,15 @@ struct Options {
   double cheb_ratio = 20.0;
   double rr_drop = 1e-6;   // pivot threshold of the rank-revealing Rayleigh-Ritz (basis conditioning <= 1/drop)
   uint64_t eps_seed = 0;
+  // Memory-bounded set-up (-geneo_eig_group_rows / -geneo_eig_mem_gb): LOBPCG carries ~30 m doubles per local row (m = block
+  // width; 7.7 KB per row at m = 32) next to the A_Neu hierarchy -- eight 6.5 M-row subdomains of the 368^3 benchmark on
+  // ONE GPU would need 400 GB.  When the rank's subdomains exceed the budget they are eigensolved in consecutive groups
+  // (each group: its own fine matrices, A_Neu hierarchy and basis blocks, released before the next one starts); the
+  // per-subdomain iteration is independent of its neighbours in the batch, so the eigenpairs are the ungrouped ones.
+  //   eig_group_rows > 0: at most this many local rows per group (a subdomain is never split);  0: from the budget
+  //   eig_mem_gb     > 0: device-memory budget of one group's eigensolve in GiB;  0: 35 % of the card (unknown card: one group)
+  int eig_group_rows = 0;
+  double eig_mem_gb = 0.0;
   // -dls1_ : local "direct" solve replaced by batched Jacobi-PCG driven to a tight tolerance
   double dls1_rtol = 1e-12;
   int dls1_max_it = 20000;
@@ -75,6 +88,7 @@ struct Info {                 // public counters / timers of geneoContext (hdr/g
   double setupTime = 0, solveTime = 0;
   long long spmv_calls = 0;
   int amg_levels = 0, amg_on_device = 0;
+  int eig_groups = 1;          // consecutive subdomain groups the eigensolve ran in (memory-bounded set-up)
   double amg_operator_complexity = 0.0, amgSetupTime = 0.0;
   int nullPivotsLoc = 0;
 };
@@ -157,6 +171,7 @@ class PC {
   std::vector<int> ksub, zoff;
   int kmax = 0, dimE = 0;
   double* d_yE = nullptr;
+  double *d_EL = nullptr, *d_ELT = nullptr;   // Cholesky factor of E and its transpose on the device (coarse_solve_local)
   std::vector<double> Efac, EfacT;
   std::vector<int> Epiv;
   bool E_chol = true;
@@ -166,6 +181,10 @@ class PC {
   struct Amg1Pending;
   std::unique_ptr<Amg1Pending> pend1;   // level-1 hierarchy whose host set-up is still running
   int finish_amg1();
+  bool eig_only = false;       // a group's temporary PC (eigen_grouped): the set-up stops behind the eigensolve
+  std::vector<int> eig_groups; // boundaries of the subdomain groups of this set-up ({0, ns}: one group = the plain path)
+  std::vector<int> plan_eig_groups() const;
+  int eigen_grouped();
   std::map<int, void*> cg_graphs;   // HIP graphs of an inner-PCG chunk, by chunk length (local_solve)
   int cg_long_len = 0;         // length of the first chunk of a local solve once the first solve of this set-up is known (0: not yet, -1: never)
   bool cg_graph_failed = false;

@@ -144,6 +144,10 @@ PetscErrorCode GeneoDecompCreate(int nbNode, int nbElem, int W, const int* nodes
     d->nbits.assign((size_t)nbNode * words, 0);
     d->ebits.assign((size_t)nbElem * words, 0);
     auto bit = [&](uint64_t* p, int part) { p[part >> 6] |= 1ull << (part & 63); };
+    // every node slot is either -1 (unused) or a node of the mesh, in both modes (the driver's "bad element" errors):
+    // the loops below index per-node arrays with them
+    for (size_t k = 0; k < (size_t)nbElem * W; ++k)
+      if (nodes[k] < -1 || nodes[k] >= nbNode) { delete d; return 1; }
     for (int e = 0; e < nbElem; ++e) {
       uint64_t* eb = &d->ebits[(size_t)e * words];
       if (dual) {

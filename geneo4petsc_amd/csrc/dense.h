@@ -149,11 +149,15 @@ inline void cholesky_solve_lu(const std::vector<double>& l, const std::vector<do
     for (int k = 0; k < i; ++k) s -= li[k] * x[k];
     x[i] = s / li[i];
   }
-  for (int i = n - 1; i >= 0; --i) {
-    const double* ui = u.data() + (size_t)i * n;
-    double s = x[i];
-    for (int k = i + 1; k < n; ++k) s -= ui[k] * x[k];
-    x[i] = s / ui[i];
+  // backward sweep column by column, from the last unknown down (x_i -= L_ki x_k for k = n - 1, n - 2, ..): the order
+  // the device kernel of the same solve uses (bk::chol_solve), so that both produce the same bits; column k of L^T is
+  // row k of L, contiguous
+  (void)u;
+  for (int k = n - 1; k >= 0; --k) {
+    const double* lk = l.data() + (size_t)k * n;
+    const double xk = x[k] / lk[k];
+    x[k] = xk;
+    for (int i = 0; i < k; ++i) x[i] -= lk[i] * xk;
   }
 }
 

@@ -189,6 +189,8 @@ typedef struct {
   double amg_operator_complexity, amgSetupTime;
   int nullPivotsLoc;                    /* null pivots detected and fixed in the local factorisations of this set-up (singular
                                            subdomain matrices; the reference's MUMPS settings of tuneSolver, geneo.cpp:76-92) */
+  int eigGroups;                        /* consecutive subdomain groups the local eigensolves of this set-up ran in (1: all at once;
+                                           > 1: memory-bounded set-up, -geneo_eig_group_rows / -geneo_eig_mem_gb) */
 } GeneoInfo;
 PetscErrorCode PCGenEOGetInfo(GENEO_PC pc, GeneoInfo* info);
 /* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */
@@ -305,6 +307,11 @@ PetscErrorCode GeneoSpmvProfileStop(double* ms_sum, double* bytes_sum, long long
  * 2 MFMA Gram (S^T T), 3 MFMA block update (S C).  Start ... the library's work ... Stop, then Get per class: summed
  * kernel ms, algorithmic bytes and flops of the SAMPLED launches, their number and the number of launches seen. */
 PetscErrorCode GeneoKernelProfileStart(int every, double spmv_min_bytes);
+/* Device memory of the library's own blocks, in bytes (any pointer may be NULL): handed out now, their high-water mark,
+ * the high-water mark of handed out + parked in the caching allocator (the library's footprint on the card), parked now,
+ * and hipMemGetInfo's free / total.  reset_peaks != 0 restarts both high-water marks at the current state. */
+PetscErrorCode GeneoDeviceMemInfo(double* live, double* live_peak, double* footprint_peak, double* cached, double* dev_free,
+                                  double* dev_total, int reset_peaks);
 PetscErrorCode GeneoKernelProfileStop(void);
 PetscErrorCode GeneoKernelProfileGet(int kernel_class, double* ms_sum, double* bytes_sum, double* flops_sum,
                                      long long* nsampled, long long* nlaunch);

@@ -158,9 +158,75 @@ class Subdomain:
     a_dir: Optional[sp.csr_matrix] = None          # optional pcADirLoc
 
 
-def _inertia_negative_count(m: sp.csr_matrix) -> tuple:
+class _PermutedLU:
+    """Exact sparse LU of P A P^T for a GIVEN fill-reducing permutation (SuperLU told to keep it: NATURAL column order,
+    diagonal pivots), with solve() in the original numbering.  Same factorisation as spla.splu(A) up to the elimination
+    order -- i.e. up to rounding --, at a fraction of the fill when the permutation is a geometric nested dissection of a
+    structured subdomain (67^3 rows: COLAMD does not fit this container's memory eight times over, this does).  Only used
+    when GenEOOracle.fill_perms is set (the headline-grid goldens, tests/golden/make_headline_goldens.py)."""
+
+    def __init__(self, m, perm):
+        self.perm = np.asarray(perm)
+        mp = m.tocsr()[self.perm][:, self.perm].tocsc()
+        self.lu = spla.splu(mp, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+
+    def solve(self, b):
+        x = np.empty_like(b, dtype=np.float64)
+        x[self.perm] = self.lu.solve(np.asarray(b, dtype=np.float64)[self.perm])
+        return x
+
+
+def nested_dissection_box(dims) -> np.ndarray:
+    """Geometric nested dissection of an nx x ny x nz box in lexicographic numbering (x fastest): the two halves first,
+    the separating plane (orthogonal to the longest side) last, recursively; boxes of <= 64 nodes in natural order.
+    Returns perm with perm[new] = old."""
+    nx, ny, nz = [int(d) for d in dims]
+    idx = np.arange(nx * ny * nz).reshape(nz, ny, nx)
+    out = []
+
+    def rec(block):
+        if block.size <= 64:
+            out.append(block.ravel())
+            return
+        ax = int(np.argmax(block.shape))
+        mid = block.shape[ax] // 2
+        sl = [slice(None)] * 3
+        sl[ax] = slice(0, mid)
+        rec(block[tuple(sl)])
+        sl[ax] = slice(mid + 1, None)
+        rec(block[tuple(sl)])
+        sl[ax] = slice(mid, mid + 1)
+        out.append(block[tuple(sl)].ravel())
+
+    rec(idx)
+    return np.concatenate(out)
+
+
+def nd_perm_for_grid_subdomain(l2g, n, dim=3) -> np.ndarray:
+    """nested-dissection permutation of a subdomain of the n^dim grid: the dissection of its bounding box restricted to
+    the nodes the subdomain holds (a block of the structured partition plus overlap layers grown by element adjacency is a
+    box with stepped faces; planes of the box still separate it).  perm[new] = local index (ascending global ids)."""
+    g = np.asarray(l2g, dtype=np.int64)
+    c = [(g // n ** a) % n for a in range(3)] if dim == 3 else [g % n, g // n, np.zeros_like(g)]
+    lo = [int(ci.min()) for ci in c]
+    dims = [int(ci.max()) - l + 1 for ci, l in zip(c, lo)]
+    box = (c[0] - lo[0]) + dims[0] * ((c[1] - lo[1]) + dims[1] * (c[2] - lo[2]))
+    local_of = np.full(dims[0] * dims[1] * dims[2], -1, dtype=np.int64)
+    local_of[box] = np.arange(len(g))
+    perm = local_of[nested_dissection_box(dims)]
+    perm = perm[perm >= 0]
+    assert len(perm) == len(g)
+    return perm
+
+
+def _inertia_negative_count(m: sp.csr_matrix, perm=None) -> tuple:
     """MatGetInertia of the LDL^T factor (geneo.cpp:491): (#neg, #zero, #pos) eigenvalues."""
     n = m.shape[0]
+    if perm is not None and n > 1500:
+        lu = _PermutedLU(m, perm).lu
+        if np.array_equal(lu.perm_r, np.arange(n)):
+            d = lu.U.diagonal()
+            return int(np.sum(d < 0)), int(np.sum(d == 0)), int(np.sum(d > 0))
     if n <= 1500:
         w = sla.eigvalsh(m.toarray())
         tol = 1e-13 * max(1.0, float(np.max(np.abs(w))))
@@ -207,6 +273,7 @@ class GenEOOracle:
         self.dense_limit = 1500
         self.arpack_seed = 20181  # start vector of the literal-mode ARPACK runs (see _eigen_solve)
         self.exact_eigs = False   # pencils above dense_limit: ARPACK at -els2_eps_tol (the reference's call) | certified exact
+        self.fill_perms = None    # per subdomain: fill-reducing permutation for every sparse LU of that subdomain (_PermutedLU)
 
     # -- operators -------------------------------------------------------------------
     def matmult(self, x: np.ndarray) -> np.ndarray:
@@ -241,7 +308,7 @@ class GenEOOracle:
             self.D.append(1.0 / s.mult.astype(np.float64) if need_pou else None)
         for p in range(self.P):                                      # setUpLevel1, geneo.cpp:126-160
             m = self.a_rob[p] if o.lvl1ORAS else self.a_dir[p]
-            self.lu1.append(spla.splu(m.tocsc()))
+            self.lu1.append(self._lu(p, m))
         if o.lvl2:
             self._build_coarse_space()                               # setUpLevel2, geneo.cpp:1544
             if b is None:
@@ -250,6 +317,12 @@ class GenEOOracle:
         else:
             self.x0 = np.zeros(self.N)
         return self
+
+    def _lu(self, p, m):
+        """exact LU of a matrix of subdomain p (MUMPS in the reference, geneo.cpp:94-124; SuperLU here)"""
+        if self.fill_perms is not None:
+            return _PermutedLU(m, self.fill_perms[p])
+        return spla.splu(m.tocsc())
 
     def _robin(self, s: Subdomain, a_dir):
         """createRobinMatrix, geneo.cpp:1613-1670 (dense border block incl. explicit zeros)."""
@@ -270,7 +343,7 @@ class GenEOOracle:
     def _estimate_nev(self, p, a, b, param, pb) -> int:
         """estimateNumberOfEigenValues, geneo.cpp:502-560."""
         syl = (a - param * b).tocsr()
-        neg, _null, pos = _inertia_negative_count(syl)
+        neg, _null, pos = _inertia_negative_count(syl, None if self.fill_perms is None else self.fill_perms[p])
         est = neg if pb == "tau" else pos
         n = len(self.subs[p].l2g)
         if est > n:
@@ -280,7 +353,7 @@ class GenEOOracle:
         self.estimDimELoc[p] += est
         return est
 
-    def _eigen_solve(self, a, b, nev, pb):
+    def _eigen_solve(self, a, b, nev, pb, p=None):
         """eigenLocalSolve, geneo.cpp:626-744 (without the tau/gamma filter)."""
         n = a.shape[0]
         tol = self.o.eps_tol
@@ -296,8 +369,9 @@ class GenEOOracle:
                 order = np.argsort(-np.abs(w), kind="stable")
             order = order[:min(nev, n)]
             return w[order], v[:, order]
+        perm = None if (self.fill_perms is None or p is None) else self.fill_perms[p]
         if self.exact_eigs and pb == "tau":
-            return self._eigen_solve_complete(a, b, nev)
+            return self._eigen_solve_complete(a, b, nev, perm)
         # fixed start vector: ARPACK's own random start continues one Fortran RNG stream across calls, so the same
         # pencil would give different bases depending on what ran before (SLEPc seeds its EPS start vector once)
         kw = {"v0": np.random.default_rng(self.arpack_seed).random(n) + 0.5}
@@ -305,6 +379,9 @@ class GenEOOracle:
             kw["maxiter"] = self.o.eps_max_it * n
         ncv = min(n - 1, max(2 * nev + 1, 20))
         if pb == "tau":
+            if perm is not None:      # shift-invert through the permuted LU of A (sigma = 0): same operator, less fill
+                lu = _PermutedLU(a, perm)
+                kw["OPinv"] = spla.LinearOperator(a.shape, matvec=lu.solve, dtype=np.float64)
             w, v = spla.eigsh(a.tocsc(), k=nev, M=b.tocsc(), sigma=0.0, which="LM", tol=tol, ncv=ncv, **kw)
             order = np.argsort(np.abs(w), kind="stable")
         else:
@@ -312,7 +389,7 @@ class GenEOOracle:
             order = np.argsort(-np.abs(w), kind="stable")
         return w[order], v[:, order]
 
-    def _eigen_solve_complete(self, a, b, nev):
+    def _eigen_solve_complete(self, a, b, nev, perm=None):
         """The nev lowest eigenpairs of a pencil too large for LAPACK, to machine precision AND provably complete:
         ARPACK shift-invert (the solver SLEPc drives for the reference, geneo.cpp:649-663) run with tol = 0 and a
         guard of extra pairs, then Sylvester's law of inertia on A - s B (the reference's own device, geneo.cpp:452-500)
@@ -321,8 +398,12 @@ class GenEOOracle:
         n = a.shape[0]
         k = min(n - 2, nev + 12)
         ac, bc = a.tocsc(), b.tocsc()
+        kw = {}
+        if perm is not None:
+            lu = _PermutedLU(a, perm)
+            kw["OPinv"] = spla.LinearOperator(a.shape, matvec=lu.solve, dtype=np.float64)
         while True:
-            w, v = spla.eigsh(ac, k=k, M=bc, sigma=0.0, which="LM", tol=0, ncv=min(n - 1, max(3 * k, 60)))
+            w, v = spla.eigsh(ac, k=k, M=bc, sigma=0.0, which="LM", tol=0, ncv=min(n - 1, max(3 * k, 60)), **kw)
             order = np.argsort(np.abs(w), kind="stable")
             w, v = w[order], v[:, order]
             below = None
@@ -331,7 +412,7 @@ class GenEOOracle:
                     shift, below = 0.5 * (w[j] + w[j - 1]), j
                     break
             if below is not None:
-                neg, _null, _pos = _inertia_negative_count((a - shift * b).tocsr())
+                neg, _null, _pos = _inertia_negative_count((a - shift * b).tocsr(), perm)
                 if neg == below:
                     return w[:nev], v[:, :nev]
             if k >= n - 2:
@@ -348,7 +429,7 @@ class GenEOOracle:
                 nev = est                                    # :861-863
         if o.cut > 0 and nev > o.cut:                        # :871-879
             nev = o.cut
-        w, v = self._eigen_solve(a, b, nev, pb)
+        w, v = self._eigen_solve(a, b, nev, pb, p)
         self.candidates[p] = (self.candidates[p] or []) + list(w)
         my_vals, my_vecs = [], []
         for k in range(len(w)):                              # :709-722

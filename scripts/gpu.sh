@@ -31,7 +31,7 @@ case $task in
 import json, sys
 try:
     j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    keep = ["value", "ms_per_step", "setup_s", "solve_s", "iterations", "dimE", "eig_iterations", "local_solve_cg_iterations",
+    keep = ["value", "ms_per_step", "setup_s", "solve_s", "iterations", "dimE", "eig_iterations", "local_solve_cg_iterations", "device_mem_peak_gb", "eig_groups", "host_prep_s", "scaling",
             "setup_breakdown_s", "solve_breakdown_s", "parity_sample"]
     print(json.dumps({k: j.get(k) for k in keep}))
     print("roofline", json.dumps(j.get("roofline")))

@@ -193,3 +193,50 @@ def check_singular_neumann_case(lib, n, argv):
     assert np.linalg.norm(x - xs) <= 1e-6 * np.linalg.norm(xs)
     pc.destroy()
     return info
+
+
+def check_grouped_eigensolve(lib, n=14, overlap=2, extra=(), group_rows=(1, 3000), exact=True):
+    """Memory-bounded set-up (-geneo_eig_group_rows): the rank's subdomains eigensolved in consecutive groups, each with its
+    own A_Neu hierarchy and LOBPCG blocks.  A subdomain's iteration depends on nothing outside its own rows (start block
+    from its global id and local row, its own Gershgorin bounds in the hierarchy, per-subdomain Rayleigh-Ritz and
+    freezing), so every INTEGER the set-up produces -- kept counts, dimE, Nicolaides, the LOBPCG iteration count -- and the
+    PCG count of the solve that follows are those of the all-at-once path.
+    exact=True (host simulator: one kernel form per operation): eigenvalues, E, the residual history and the solution are
+    BIT-IDENTICAL.  exact=False (the GPU: the SpMV form of a coarse level -- slices or lanes-per-row, two summation
+    orders -- is picked from the row count of the whole batch): floats agree to rounding, eigenvalues to 1e-10 relative
+    (north_star's bar), the worst differences are returned for the test to print."""
+    mesh, dec, a, b = grid_case(n=n, dim=3, parts=(2, 2, 2), overlap=overlap)
+    argv = bench_argv(extra)
+    runs = []
+    for rows in (0,) + tuple(group_rows):
+        pc = run_pc(lib, mesh, dec, argv + (["-geneo_eig_group_rows", str(rows)] if rows else []), b)
+        x, its, rnorm, reason = pc.solve(b)
+        info = pc.info()
+        runs.append(dict(ev=[pc.eigenvalues(s) for s in range(8)], cand=[pc.eigenvalues(s, candidates=True) for s in range(8)],
+                         E=pc.E(), dims=list(pc.local_dims()), its=its, x=x, reason=reason, info=info, hist=pc.residual_history()))
+        pc.destroy()
+    base = runs[0]
+    assert base["info"]["eigGroups"] == 1 and base["reason"].startswith("KSP_CONVERGED")
+    worst = {"eigenvalue": 0.0, "E": 0.0, "x": 0.0}
+    for rows, r in zip(group_rows, runs[1:]):
+        assert r["info"]["eigGroups"] > 1, (rows, r["info"]["eigGroups"])
+        assert r["dims"] == base["dims"] and r["info"]["dimE"] == base["info"]["dimE"]
+        assert r["info"]["eig_iterations"] == base["info"]["eig_iterations"]
+        assert r["info"]["nicolaidesLoc"] == base["info"]["nicolaidesLoc"]
+        assert r["its"] == base["its"] and r["reason"] == base["reason"], (rows, r["its"], base["its"])
+        for s in range(8):
+            if exact:
+                assert np.array_equal(r["ev"][s], base["ev"][s]), (rows, s)
+                assert np.array_equal(r["cand"][s], base["cand"][s]), (rows, s)
+            else:
+                np.testing.assert_allclose(r["ev"][s], base["ev"][s], rtol=1e-10, atol=1e-13)
+                worst["eigenvalue"] = max(worst["eigenvalue"], float(np.max(np.abs(r["ev"][s] - base["ev"][s]) / np.abs(base["ev"][s]))))
+        if exact:
+            assert np.array_equal(r["E"], base["E"]), rows
+            assert np.array_equal(r["hist"], base["hist"]) and np.array_equal(r["x"], base["x"]), rows
+        else:
+            worst["E"] = max(worst["E"], float(np.linalg.norm(r["E"] - base["E"]) / np.linalg.norm(base["E"])))
+            worst["x"] = max(worst["x"], float(np.linalg.norm(r["x"] - base["x"]) / np.linalg.norm(base["x"])))
+            assert worst["E"] <= 1e-8 and worst["x"] <= 1e-6, worst
+    assert runs[1]["info"]["eigGroups"] == 8
+    return runs, worst

@@ -97,6 +97,10 @@ void side_stream_end() {}
 void* alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { free(p); }
 void alloc_stats(double* a, double* f, long long* n) { *a = 0; *f = 0; *n = 0; }
+void mem_info(double* live, double* live_peak, double* footprint_peak, double* cached, double* dev_free, double* dev_total, bool) {
+  for (double* p : {live, live_peak, footprint_peak, cached, dev_free, dev_total})
+    if (p) *p = 0.0;   // no device: the memory-bounded set-up is driven by its explicit option only
+}
 void h2d(void* d, const void* h, size_t b) { if (b) memcpy(d, h, b); }
 void d2h(void* h, const void* d, size_t b) { if (b) memcpy(h, d, b); }
 void d2d(void* d, const void* s, size_t b) { if (b) memmove(d, s, b); }
@@ -621,6 +625,22 @@ void z_apply(const Chunks& c, const double* Z, const int64_t* zbase, const int* 
 }
 void set_mfma(bool) {}
 bool set_variant(const char*, int) { return false; }
+bool chol_solve(const double* L, const double* LT, int n, double* y) {   // the loops of dense::cholesky_solve_lu
+  (void)LT;
+  for (int i = 0; i < n; ++i) {
+    const double* li = L + (size_t)i * n;
+    double s = y[i];
+    for (int k = 0; k < i; ++k) s -= li[k] * y[k];
+    y[i] = s / li[i];
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const double* lk = L + (size_t)k * n;
+    const double xk = y[k] / lk[k];
+    y[k] = xk;
+    for (int i = 0; i < k; ++i) y[i] -= lk[i] * xk;
+  }
+  return true;
+}
 void* pinned_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 8); }
 void pinned_free(void* p) { std::free(p); }
 void h2d_async(void* d, const void* h, size_t bytes) { if (bytes) std::memcpy(d, h, bytes); }

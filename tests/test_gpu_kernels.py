@@ -558,3 +558,4 @@ def test_library_threads_run_on_the_librarys_device(lib):
     finally:
         assert lib.GeneoSetDevice(0) == 0
     assert lib.GeneoThreadDeviceCheck() == 0
+

@@ -293,3 +293,73 @@ def test_singular_neumann_matrices_get_null_pivot_fixing(lib):
     1 / rounding and LOBPCG never converges.  What is compared: cases.check_singular_neumann_case."""
     argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "gmres"] + TIGHT
     cases.check_singular_neumann_case(lib, 12, argv)
+
+
+def test_memory_bounded_setup_groups_give_the_ungrouped_result(lib):
+    """-geneo_eig_group_rows: eigensolve group by group (one subdomain per group, and three groups) == all at once, to the bit."""
+    cases.check_grouped_eigensolve(lib, n=14)
+
+
+def test_memory_bounded_setup_without_cut_and_with_the_chebyshev_eigensolver(lib):
+    """the same with the deflated-restart path (no -geneo_cut: more pairs below tau than one block holds) inside a group"""
+    mesh, dec, a, b = cases.grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1)
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.6", "-ksp_type", "gmres"] + TIGHT
+    res = []
+    for extra in ([], ["-geneo_eig_group_rows", "1000"]):
+        pc = cases.run_pc(lib, mesh, dec, argv + extra, b)
+        info = pc.info()
+        res.append(([pc.eigenvalues(s) for s in range(8)], pc.E(), info["dimE"], info["eigGroups"]))
+        pc.destroy()
+    assert res[0][3] == 1 and res[1][3] == 4 and res[0][2] == res[1][2] == 632
+    for s in range(8):
+        assert np.array_equal(res[0][0][s], res[1][0][s])
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_setup_failure_with_one_oras_block_joins_the_hierarchy_thread(lib):
+    """one subdomain per rank + ORAS + AMG local solves: the level-1 hierarchy thread reads the Robin matrix; an
+    eigensolve that fails (here: a block narrower than -geneo_cut, refused before the first iteration) must come back as an error code with that thread joined
+    and the matrix still alive -- it now lives in the pending object, not on setup()'s stack."""
+    mesh, dec, a, b = cases.grid_case(n=10, dim=3, parts=(1, 1, 1), overlap=1)
+    argv = ["-geneo_lvl", "ORAS,1", "-geneo_optim", "0.5", "-geneo_tau", "0.2", "-geneo_cut", "20", "-els2_eps_block", "16",
+            "-ksp_type", "gmres"]
+    from geneo4petsc_amd.pc import GenEOPC, GenEOError
+    for _ in range(3):
+        pc = GenEOPC(lib)
+        pc.set_from_options(argv)
+        pc.set_sizes(mesh.nbNode, 1)
+        d = dec.domains[0]
+        pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+        with pytest.raises(GenEOError, match="larger than the LOBPCG block"):
+            pc.setup(b)
+        pc.destroy()
+
+
+def test_nicolaides_zero_window_option(lib):
+    """-geneo_nicolaides_zero X: the window below which the smallest kept eigenvalue counts as the zero eigenvalue
+    (geneo.cpp:896-899 tests min >= DBL_EPSILON, i.e. X = 1; the default is 100, see core.cpp).  Outside the window the two
+    rules agree: on a regular problem X = 1 changes nothing.  On exactly singular Neumann matrices (--inpEps 0) the rule
+    with X = 0 fires exactly on the subdomains whose computed zero eigenvalue came out >= 0 -- the reference's behaviour
+    there is decided by the sign of a rounding error, which is why the default window exists."""
+    mesh, dec, a, b = cases.grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1)
+    argv = ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", "gmres"] + TIGHT
+    ref = cases.run_pc(lib, mesh, dec, argv, b)
+    lit = cases.run_pc(lib, mesh, dec, argv + ["-geneo_nicolaides_zero", "1"], b)
+    assert ref.info()["nicolaidesLoc"] == lit.info()["nicolaidesLoc"] and np.array_equal(ref.E(), lit.E())
+    ref.destroy()
+    lit.destroy()
+    mesh, dec, a, b = cases.grid_case(n=12, dim=3, parts=(2, 2, 2), overlap=1, inp_eps=0.0)
+    wide = cases.run_pc(lib, mesh, dec, argv + ["-geneo_nicolaides_zero", "1e9"], b)
+    assert wide.info()["nicolaidesLoc"] == 0
+    lam0 = [float(np.min(wide.eigenvalues(s, candidates=True))) for s in range(8)]
+    wide.destroy()
+    none = cases.run_pc(lib, mesh, dec, argv + ["-geneo_nicolaides_zero", "0"], b)
+    floating = [s for s in range(8) if abs(lam0[s]) < 1e-10]
+    assert len(floating) == 4
+    assert none.info()["nicolaidesLoc"] == sum(1 for s in floating if lam0[s] >= 0.0)
+    none.destroy()
+    from geneo4petsc_amd.pc import GenEOPC, GenEOError
+    pc = GenEOPC(lib)
+    with pytest.raises(GenEOError, match="nicolaides_zero"):
+        pc.set_from_options(["-geneo_nicolaides_zero", "-3"])
+    pc.destroy()
