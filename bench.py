@@ -245,8 +245,17 @@ def cpu_baseline(args, doms, lib):
     out["cores"] = int(olib.oracle_num_threads())
     out["sample"] = "CSR SpMV of the %d-row / %d-nnz local matrix of %d of the rank's %d subdomains, %d repetitions (C + OpenMP)" % (
         a.shape[0], a.nnz, len(take), len(doms), reps)
-    # (2) the oracle's GenEO setup + PCG solve (exact LU local solves, ARPACK shift-invert at -els2_eps_tol) on a bounded sample
-    #     of the same workload -- same operator, same options, smaller grid -- and the GPU library beside it
+    # (2) the SAME ALGORITHM compiled for the host cores: the library's own orchestration (LOBPCG with
+    #     the AMG V-cycle, batched AMG-PCG local solves, E, PCG) over the OpenMP build of the test backend
+    #     (tests/hostsim: -O3 -mavx2 -mfma -fopenmp), at a REAL size: BASELINE configs[1], 126^3 = 2.0 M DoF in 8 subdomains
+    #     with the bench's own options -- the whole set-up + solve where the box has >= 64 cores, otherwise ONE of its eight
+    #     subdomains (67^3-class block, 286 k rows) as a stand-alone problem.  Bench infrastructure: never a product backend.
+    try:
+        out["geneo_sample"] = cpu_geneo_sample(args)
+    except Exception as e:
+        out["geneo_sample"] = {"error": repr(e)}
+    # (3) the oracle's GenEO setup + PCG solve (exact LU local solves, ARPACK shift-invert at -els2_eps_tol) on a small
+    #     grid of the same workload and the GPU library beside it: the parity sample of the line
     try:
         from geneo4petsc_amd import decomp
         from geneo4petsc_amd.pc import GenEOPC
@@ -267,10 +276,10 @@ def cpu_baseline(args, doms, lib):
         t1 = time.perf_counter()
         res = go.solve(orc, bs, "cg", rtol=args.rtol)
         t2 = time.perf_counter()
-        out["geneo_sample"] = {"grid": "%d^3 (%d DoF), 8 subdomains" % (ns, mesh.nbNode), "setup_s": t1 - t0,
-                               "solve_s": t2 - t1, "iterations": res.its, "dimE": int(orc.dimE), "cores": int(orc.workers),
-                               "note": "set-up: the subdomains' eigenproblems on %d worker processes (one per subdomain, as the "
-                                       "reference's MPI ranks); local LU factorisations and the PCG loop on one core" % orc.workers}
+        out["oracle_sample"] = {"grid": "%d^3 (%d DoF), 8 subdomains" % (ns, mesh.nbNode), "setup_s": t1 - t0,
+                                "solve_s": t2 - t1, "iterations": res.its, "dimE": int(orc.dimE), "cores": int(orc.workers),
+                                "note": "the oracle (exact LU + ARPACK): eigenproblems on %d worker processes (one per subdomain, "
+                                        "as the reference's MPI ranks); local LU factorisations and the PCG loop on one core" % orc.workers}
         pc = GenEOPC(lib)
         pc.set_from_options(argv)
         pc.set_sizes(mesh.nbNode, 8)
@@ -289,8 +298,58 @@ def cpu_baseline(args, doms, lib):
                                 "gpu_setup_s": gi["setupTime"], "gpu_solve_s": gi["solveTime"]}
         pc.destroy()
     except Exception as e:     # the SpMV leg above is the contract; this leg is extra context
-        out["geneo_sample"] = {"error": repr(e)}
+        out["oracle_sample"] = {"error": repr(e)}
     return out
+
+
+def cpu_geneo_sample(args):
+    """libgeneopc's host orchestration on the OpenMP build of the test backend, timed at 126^3 (see cpu_baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+    import build as hs_build
+    from geneo4petsc_amd import _lib as L, decomp
+    from geneo4petsc_amd.pc import GenEOPC
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    hlib = L.bind(hs_build.build_omp())
+    assert hlib.GeneoBackendName() == b"host-openmp"
+    n, parts = 126, (2, 2, 2)
+    argv = geneo_argv(args)
+    whole = cores >= 64
+    t0 = time.perf_counter()
+    pc = GenEOPC(hlib)
+    if whole:
+        doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True) for s in range(8)]
+        npart = decomp.structured_node_partition(n, 3, parts)
+        b = np.zeros(n ** 3)
+        for d in doms:
+            rows = d.a_dir @ (d.l2g.astype(np.float64) + 1.0)
+            sel = npart[d.l2g] == d.gid
+            b[d.l2g[sel]] = rows[sel]
+        pc.set_from_options(argv)
+        pc.set_sizes(n ** 3, 8)
+        for d in doms:
+            pc.add_subdomain(d.gid, d.l2g, d.mult, d.a_neu, d.a_dir)
+        what = "the whole %d^3 = %d DoF problem in 8 subdomains: full set-up + PCG solve" % (n, n ** 3)
+    else:
+        d = decomp.decompose_grid_domain(n, 3, parts, args.overlap, 0, native=True)
+        nloc = len(d.l2g)
+        b = d.a_neu @ (np.arange(nloc, dtype=np.float64) + 1.0)
+        pc.set_from_options(argv + ["-ksp_max_it", "25", "-ksp_rtol", "1e-30", "-ksp_atol", "1e-300"])
+        pc.set_sizes(nloc, 1)
+        pc.add_subdomain(0, np.arange(nloc), d.mult, d.a_neu, d.a_dir)
+        what = ("ONE of the eight subdomains of the %d^3 decomposition (%d local rows) as a stand-alone problem: its whole "
+                "set-up (hierarchies, LOBPCG, Z) + 25 PCG iterations on its local operator" % (n, nloc))
+    prep = time.perf_counter() - t0
+    pc.setup(b)
+    x, its, _, reason = pc.solve(b)
+    info = pc.info()
+    pc.destroy()
+    return {"kind": "port", "what": what, "setup_s": info["setupTime"], "solve_s": info["solveTime"],
+            "setup_plus_solve_s": info["setupTime"] + info["solveTime"], "iterations": int(its), "converged": reason,
+            "dimE": int(info["dimE"]), "eig_iterations": int(info["eig_iterations"]), "cores": int(cores),
+            "host_prep_s": prep, "options": " ".join(argv),
+            "build": "tests/hostsim/backend_host.cpp + csrc/core.cpp, amg.cpp: g++ -O3 -mavx2 -mfma -fopenmp -DGENEO_HOST_OMP"}
 
 
 def one_rank_of(args):
@@ -674,11 +733,11 @@ def main():
         traffic_note = None
         try:
             import hashlib
-            pmc_path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.json")
+            pmc_path = os.path.join(ROOT, "profiles", "r04_hbm_traffic_pmc.json")
             prof = json.load(open(pmc_path))
             sha = hashlib.sha256(open(os.path.join(ROOT, "geneo4petsc_amd", "csrc", "backend_hip.hip"), "rb").read()).hexdigest()[:16]
             if prof.get("kernel_source_sha16") != sha:
-                traffic_note = ("profiles/r03_hbm_traffic_pmc.json was measured on kernel source %s, this is %s: stale, not applied"
+                traffic_note = ("profiles/r04_hbm_traffic_pmc.json was measured on kernel source %s, this is %s: stale, not applied"
                                 % (prof.get("kernel_source_sha16"), sha))
                 print("bench.py: " + traffic_note, file=sys.stderr, flush=True)
                 prof = {}
@@ -690,13 +749,28 @@ def main():
                     k["traffic"] = hits[0]["traffic_over_algorithmic"] * k["algorithmic_bytes_per_launch"]
         except Exception as e:
             traffic_note = "no PMC profile applied: %r" % (e,)
+        # MFMA utilisation of the Rayleigh-Ritz kernels (north_star: "MFMA utilisation for the Rayleigh-Ritz step"): PMC
+        # passes of scripts/pmc.py (scripts/gpu.sh pmcm), attached to the two MFMA rows under the same staleness rule
+        try:
+            mp = json.load(open(os.path.join(ROOT, "profiles", "r04_mfma_pmc.json")))
+            if mp.get("kernel_source_sha16") == sha:
+                for k in kernels:
+                    key = k["kernel"].split(" ")[0]
+                    hits = {name: v for name, v in mp.items() if isinstance(v, dict) and name.startswith(key) and "MfmaUtil" in v}
+                    if hits:
+                        k["mfma_util_percent"] = {name: v["MfmaUtil"] for name, v in hits.items()}
+                        k["mfma_util_source"] = "profiles/r04_mfma_pmc.json (rocprofv3 --pmc MfmaUtil, same kernel source)"
+            elif rank == 0:
+                print("bench.py: profiles/r04_mfma_pmc.json is older than the kernels: MFMA utilisation not attached", file=sys.stderr, flush=True)
+        except Exception:
+            pass
         dom = max(kernels, key=lambda k: k["share_of_step"]) if kernels else None
         roof = {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS,
                 "traffic": None, "kernel": "k_spmv_sell"}
         if dom is not None:
             roof = {"bound": "hbm", "achieved": dom["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_GBs"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"),
-                    "traffic_source": ("profiles/r03_hbm_traffic_pmc.json (same kernel source): PMC traffic / algorithmic of this "
+                    "traffic_source": ("profiles/r04_hbm_traffic_pmc.json (same kernel source): PMC traffic / algorithmic of this "
                                        "kernel class (%.3f) x the in-situ algorithmic bytes per launch" % dom["traffic_over_algorithmic"])
                     if dom.get("traffic") else traffic_note,
                     "kernel": dom["kernel"], "share_of_step": dom["share_of_step"],
@@ -749,6 +823,22 @@ def main():
                                   "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
             "roofline": roof,
         }
+        # the oracle's counts at THIS grid, when a golden holds them (tests/golden/headline.json: 96^3, 126^3 at these options)
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "headline.json"))).get(str(n), {}).get("literal")
+            default_opts = (args.workload == "laplacian" and nb == 8 and args.lvl == "SRAS,1" and args.cut == 20 and args.tau == 0.35
+                            and args.eps_tol == 1e-3 and args.rtol == 1e-5 and args.overlap == 2 and not args.pc_args)
+            if gold and default_opts:
+                spread = sorted(set([gold["cg"]["its"]] + [c for v in gold.get("cg_spread", {}).values() for c in v]))
+                out["golden_at_this_grid"] = {"source": "tests/golden/headline.json (reference-literal oracle: exact LU, ARPACK at 1e-3)",
+                                              "oracle_pcg_iterations": gold["cg"]["its"], "oracle_pcg_spread_under_perturbation": spread,
+                                              "oracle_dimE": gold["dimE"], "oracle_kept": gold["realDimELoc"],
+                                              "gpu_pcg_iterations": int(its), "gpu_dimE": int(info["dimE"]),
+                                              "dimE_identical": bool(gold["dimE"] == info["dimE"]),
+                                              "pcg_count_identical": bool(gold["cg"]["its"] == int(its)),
+                                              "pcg_count_inside_oracle_spread": bool(min(spread) <= int(its) <= max(spread))}
+        except Exception:
+            pass
         if args.workload == "heat":
             # configs[3]: the same problem with plain one-level ASM (-geneo_lvl ASM,0), PCG iteration counts side by side
             pc0 = GenEOPC(lib)

@@ -367,7 +367,8 @@ static double gershgorin_rho(const HostCsr& a, std::vector<double>& dinv, const 
   double rho = 0.0;
   for (double v : rho_s) rho = std::max(rho, v);
   if (!(rho > 0)) return 2.0;
-  if (suboff.size() > 2) {
+  static const bool shared = getenv("GENEO_AMG_SHARED_RHO") != nullptr;   // A/B: the rounds-1..3 rule (one bound per level)
+  if (suboff.size() > 2 && !shared) {
     for (int s = 0; s < nsub; ++s) {
       if (!(rho_s[s] > 0.0) || rho_s[s] == rho) continue;
       const double f = rho / rho_s[s];

@@ -2171,6 +2171,38 @@ bool csr_make_lp(Csr& a, const Csr* index_owner) {
                      (const int4*)a.lp_base, (index_owner || !a.lp_col) ? (unsigned short*)nullptr : a.lp_col, a.lp_val);
   return true;
 }
+// A slice of KW <= 8 entries per row in TWO dependent memory latencies: every (col, val) pair of the slice is requested
+// before the first x gather and all gathers are in flight together (what k_spmv_sell_p8 does for the FP64 SpMV).  The
+// 4-step loop of k_spmv_sell_lp sends a 7-wide slice -- every fine-level operator of the benchmark -- through one round of
+// four and three one-at-a-time tail steps: eight dependent latencies per wave, and a wave holds one 64-row slice, so its
+// run time IS that chain (0.46-0.54 of the HBM peak while the FP64 SpMV on the same pattern reaches
+// 0.72).  The products are summed exactly as that loop sums them (KW / 4 rounds into four accumulators, the remainder
+// into the first): results are bit-identical.
+__device__ int g_lp_no_fixed = 0;       // set_variant("lp_fixed", 0): the 4-step loop for every slice (validation, A/B)
+template <int KW, int EPI, typename COLT, bool NT>
+__device__ __forceinline__ double lp_row_sum_fixed(const COLT* __restrict__ col, const float* __restrict__ val, int64_t e0,
+                                                   const int4 cb, const double* __restrict__ xin,
+                                                   const double* __restrict__ cs) {
+  int c[KW];
+  double v[KW];
+#pragma unroll
+  for (int u = 0; u < KW; ++u) {
+    c[u] = (u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e0 + 64 * u) : col[e0 + 64 * u]);
+    v[u] = (double)(NT ? __builtin_nontemporal_load(val + e0 + 64 * u) : val[e0 + 64 * u]);
+  }
+  double xv[KW];
+#pragma unroll
+  for (int u = 0; u < KW; ++u) xv[u] = (EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NG = KW / 4;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += v[4 * g + u] * xv[4 * g + u];
+#pragma unroll
+  for (int k = 4 * NG; k < KW; ++k) acc[0] += v[k] * xv[k];
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
 // WPS = 1: one wave per slice (four slices per workgroup), WPS = 4: one workgroup per slice (wide slices), as the FP64
 // kernels k_spmv_sell_epi / k_spmv_sell_wide above; summation order fixed.
 // NT: the once-read (col, val) stream of a LARGE companion is marked non-temporal, as in k_spmv_sell (the vectors of the
@@ -2216,6 +2248,22 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
   for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
   int64_t e = a + (WPS == 1 ? 0 : 64 * wv) + l;
   int k = (WPS == 1 ? 0 : wv);            // entry index of e within its row
+  const int wd = (int)((e1 - a) >> 6);    // entries per row of this slice (wave-uniform)
+  double fixed_sum = 0.0;
+  const bool fixed = (WPS == 1 && wd >= 1 && wd <= 8 && !g_lp_no_fixed);
+  if (fixed) {
+    switch (wd) {
+      case 1: fixed_sum = lp_row_sum_fixed<1, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 2: fixed_sum = lp_row_sum_fixed<2, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 3: fixed_sum = lp_row_sum_fixed<3, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 4: fixed_sum = lp_row_sum_fixed<4, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 5: fixed_sum = lp_row_sum_fixed<5, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 6: fixed_sum = lp_row_sum_fixed<6, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      case 7: fixed_sum = lp_row_sum_fixed<7, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+      default: fixed_sum = lp_row_sum_fixed<8, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
+    }
+    e = e1;                               // nothing left for the general loops below
+  }
   for (; e + STEP * (UNR - 1) < e1; e += STEP * UNR, k += WPS * UNR) {
     int c[UNR];
     double v[UNR];
@@ -2232,7 +2280,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
     const double v0 = (double)(NT ? __builtin_nontemporal_load(val + e) : val[e]);
     acc[0] += v0 * ((EPI == EPI_PRE && cs) ? xin[c0] * cs[c0] : xin[c0]);
   }
-  double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  double sum = fixed ? fixed_sum : (acc[0] + acc[1]) + (acc[2] + acc[3]);
   if (WPS == 4) {
     if (wv > 0) part[wv - 1][l] = sum;
     __syncthreads();
@@ -4804,6 +4852,12 @@ bool set_variant(const char* name, int value) {
   const std::string k(name ? name : "");
   if (k == "spgemm_fill_scan") { g_spgemm_fill_scan = value != 0; return true; }
   if (k == "gram_flat") { g_gram_flat = value != 0; return true; }
+  if (k == "lp_fixed") {
+    lazy_init();
+    const int off = value ? 0 : 1;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lp_no_fixed), &off, sizeof(int)));
+    return true;
+  }
   if (k == "spgemm_small_rows") {
     lazy_init();
     const int off = value ? 0 : 1;

@@ -183,6 +183,9 @@ class PC {
   int finish_amg1();
   bool eig_only = false;       // a group's temporary PC (eigen_grouped): the set-up stops behind the eigensolve
   std::vector<int> eig_groups; // boundaries of the subdomain groups of this set-up ({0, ns}: one group = the plain path)
+  double prepare_secs = 0.0;   // time of setup_prepare (setupTime = both halves)
+  int setup_prepare();         // first half of setup(): everything the eigensolve waits for
+  int setup_finish(const double* b_dev);   // second half: level 2 and the bookkeeping
   std::vector<int> plan_eig_groups() const;
   int eigen_grouped();
   std::map<int, void*> cg_graphs;   // HIP graphs of an inner-PCG chunk, by chunk length (local_solve)

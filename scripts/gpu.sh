@@ -65,6 +65,12 @@ PY
     f=$(find /tmp/pmc_$TAG -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp $f $O/${TAG}_$ctr.csv && wc -l $O/${TAG}_$ctr.csv
     tail -3 $O/${TAG}_$ctr.log; exit $rc ;;
+  pmcm)   # MFMA utilisation of the Rayleigh-Ritz kernels: two PMC passes of scripts/pmc.py work + the report
+    rm -rf /tmp/pmcm1_$TAG /tmp/pmcm2_$TAG
+    (cd /tmp && timeout -k 10 ${LIMIT:-400} rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d /tmp/pmcm1_$TAG -o run -- python3 $R/scripts/pmc.py work "$@" > $O/${TAG}_p1.log 2>&1) || { tail -5 $O/${TAG}_p1.log; exit 1; }
+    (cd /tmp && timeout -k 10 ${LIMIT:-400} rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmcm2_$TAG -o run -- python3 $R/scripts/pmc.py work "$@" > $O/${TAG}_p2.log 2>&1) || { tail -5 $O/${TAG}_p2.log; exit 1; }
+    python3 scripts/pmc.py mfma_report /tmp/pmcm1_$TAG /tmp/pmcm2_$TAG > $O/${TAG}_mfma.json; rc=$?
+    head -c 3000 $O/${TAG}_mfma.json; exit $rc ;;
   pmc2)   # HBM traffic of the hot kernels: two PMC passes (FETCH_SIZE, WRITE_SIZE) of scripts/pmc.py + the report
     rm -rf /tmp/pmcf_$TAG /tmp/pmcw_$TAG
     (cd /tmp && timeout -k 10 ${LIMIT:-500} rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmcf_$TAG -o run -- python3 $R/scripts/pmc.py work "$@" $O/${TAG}_work.json > $O/${TAG}_fetch.log 2>&1) || { tail -5 $O/${TAG}_fetch.log; exit 1; }

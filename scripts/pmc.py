@@ -71,6 +71,10 @@ def work(argv):
         S = np.random.default_rng(2).random((rows, 96))
         block_kernel(0, suboff, S, S, lib, reps=3)
         block_kernel(1, suboff, S, np.random.default_rng(3).random((len(doms), 96, 64)), lib, reps=3)
+        # the W rows of both Gram matrices in one pass (LOBPCG's reduced iteration: k_gram_flat<2, 3, true>) and the
+        # 32 x 32 block product of the coarse-operator assembly (k_blockmul_mfma<8>)
+        block_kernel(2, suboff, np.ascontiguousarray(S[:, :64]), S, lib, reps=3)
+        block_kernel(1, suboff, np.ascontiguousarray(S[:, :32]), np.random.default_rng(5).random((len(doms), 32, 32)), lib, reps=3)
         # the fused LOBPCG update [X P] <- S C for S, A S, B S with the residual R = A X - B X diag(lam) (one launch)
         nd = len(doms)
         Cm = np.random.default_rng(4).random((nd, 96, 64))
@@ -143,8 +147,36 @@ def report(fd, wd, alg_json):
     print(json.dumps(rep, indent=1))
 
 
+def mfma_report(dirs):
+    """per MFMA kernel: the mean of every counter the given rocprofv3 --pmc passes collected (MfmaUtil = the derived
+    metric, 100 x sum SQ_VALU_MFMA_BUSY_CYCLES / (max GRBM_GUI_ACTIVE x SIMDs), gfx94x formula as the guide notes;
+    SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = FP64 matrix flops)"""
+    import hashlib
+    rep = {"kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "geneo4petsc_amd", "csrc", "backend_hip.hip"), "rb").read()).hexdigest()[:16],
+           "method": "one rocprofv3 --pmc pass per counter set with --kernel-trace only, on scripts/pmc.py work (bench matrix, LOBPCG shapes)"}
+    acc = {}
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"]
+                if not any(t in k for t in ("k_gram_flat", "k_gram_mfma", "k_blockmul_mfma", "k_lobpcg_update32")):
+                    continue
+                short = k.split("(")[0].replace("bk::", "").replace("void ", "").strip()
+                acc.setdefault(short, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, cs in sorted(acc.items()):
+        row = {"launches": max(len(v) for v in cs.values())}
+        for c, v in cs.items():
+            row[c] = sum(v) / len(v)
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in row:
+            row["fp64_mfma_flops_per_launch"] = row["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+        rep[k] = row
+    print(json.dumps(rep, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "work":
         work(sys.argv[2:])
+    elif sys.argv[1] == "mfma_report":
+        mfma_report(sys.argv[2:])
     else:
         report(sys.argv[2], sys.argv[3], sys.argv[4])

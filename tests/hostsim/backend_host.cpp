@@ -15,10 +15,52 @@
 
 #include "backend.h"
 
+// GENEO_HOST_OMP (tests/hostsim/build.py build_omp -> libgeneopc_hostomp.so): the same loops with OpenMP over the rows --
+// the CPU baseline bench.py times beside the GPU line (`cpu_baseline.geneo_sample`, kind "port": the library's own host
+// orchestration -- LOBPCG, batched AMG-PCG, E, PCG -- on the box's host cores).  Test / bench infrastructure like the
+// serial build: geneo4petsc_amd._lib.load() accepts the "hip-gfx950" backend only.  Reductions become per-thread
+// partial sums combined in thread order (a different summation order than the serial build: its results agree with the
+// serial ones to rounding, not to the bit).
+#ifdef GENEO_HOST_OMP
+#include <omp.h>
+#define OMP_PRAGMA_(x) _Pragma(#x)
+#define OMP_ROWS OMP_PRAGMA_(omp parallel for schedule(static))
+#define OMP_SUM(v) OMP_PRAGMA_(omp parallel for schedule(static) reduction(+ : v))
+#define OMP_SUM2(v, w) OMP_PRAGMA_(omp parallel for schedule(static) reduction(+ : v, w))
+#else
+#define OMP_ROWS
+#define OMP_SUM(v)
+#define OMP_SUM2(v, w)
+#endif
+
 namespace bk {
 
 static void* g_stream = nullptr;
+#ifdef GENEO_HOST_OMP
+const char* name() { return "host-openmp"; }
+#else
 const char* name() { return "hostsim"; }
+#endif
+// G (pq doubles, zeroed here) += sum over rows i0..i1 of row_fn(i, accumulator): serial, or per-thread accumulators summed
+// in thread order
+template <class F>
+static void accumulate_rows(int i0, int i1, int pq, double* g, F row_fn) {
+  for (int e = 0; e < pq; ++e) g[e] = 0;
+#ifdef GENEO_HOST_OMP
+  const int nt = omp_get_max_threads();
+  std::vector<std::vector<double>> part(nt, std::vector<double>((size_t)pq, 0.0));
+#pragma omp parallel
+  {
+    double* my = part[omp_get_thread_num()].data();
+#pragma omp for schedule(static)
+    for (int i = i0; i < i1; ++i) row_fn(i, my);
+  }
+  for (int t = 0; t < nt; ++t)
+    for (int e = 0; e < pq; ++e) g[e] += part[t][e];
+#else
+  for (int i = i0; i < i1; ++i) row_fn(i, g);
+#endif
+}
 void set_stream(void* s) { g_stream = s; }
 void* get_stream() { return g_stream; }
 void sync() {}
@@ -41,6 +83,7 @@ double* sell_values_on(const Csr& a, const Csr& b) {
 bool spmm_dual_available(const Csr& a, int m) { return a.n > 0 && (m == 16 || m == 32 || m == 64); }
 void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* Y1, double* Y2, int ldy,
                int m) {
+  OMP_ROWS
   for (int r = 0; r < a.n; ++r)
     for (int j = 0; j < m; ++j) {
       double s1 = 0.0, s2 = 0.0;
@@ -55,7 +98,8 @@ void spmm_dual(const Csr& a, const double* v1, const double* v2, const double* X
 }
 void spmm_dual_residual(const Csr& a, const double* v1, const double* v2, const double* X, int ldx, double* R, int ldr, int m,
                         const Chunks& c, const double* lam, const double* mask) {
-  for (int s = 0; s < c.nsub; ++s)
+  for (int s = 0; s < c.nsub; ++s) {
+    OMP_ROWS
     for (int r = c.suboff[s]; r < c.suboff[s + 1]; ++r)
       for (int j = 0; j < m; ++j) {
         double s1 = 0.0, s2 = 0.0;
@@ -66,11 +110,13 @@ void spmm_dual_residual(const Csr& a, const double* v1, const double* v2, const 
         }
         R[(int64_t)r * ldr + j] = mask[s * m + j] * (s1 - lam[s * m + j] * s2);
       }
+  }
 }
 void lobpcg_update32_basis(const Chunks& c, const double* S, const double* C, const double* keep, double* T) {
-  std::vector<double> pw(32);
-  for (int s = 0; s < c.nsub; ++s)
+  for (int s = 0; s < c.nsub; ++s) {
+    OMP_ROWS
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      double pw[32];
       const double* row = S + (int64_t)i * 96;
       const double* Cs = C + (int64_t)s * 96 * 64;
       double* out = T + (int64_t)i * 96;
@@ -84,6 +130,7 @@ void lobpcg_update32_basis(const Chunks& c, const double* S, const double* C, co
       }
       for (int j = 0; j < 32; ++j) out[32 + j] = pw[j];
     }
+  }
 }
 void set_par_reduce_min(int) {}
 int get_par_reduce_min() { return 0; }
@@ -213,6 +260,7 @@ void spmv_fused_lp(const Csr&, int, const double*, double*, const double*, doubl
   throw std::runtime_error("hostsim: no single-precision companion");
 }
 void spmv(const Csr& a, const double* x, double* y) {
+  OMP_ROWS
   for (int i = 0; i < a.n; ++i) {
     double s = 0;
     for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) s += a.val[k] * x[a.col[k]];
@@ -231,6 +279,7 @@ void spmv_profile_stop(double* a, double* b, long long* c, long long* d) {
 }
 void spmm_strided(const Csr& a, const double* X, int ldx, double* Y, int ldy, int m, const double* pre,
                   const double* post) {
+  OMP_ROWS
   for (int i = 0; i < a.n; ++i)
     for (int j = 0; j < m; ++j) {
       double s = 0;
@@ -250,6 +299,7 @@ void graph_destroy(void*) {}
 bool csr_fusable(const Csr&) { return true; }
 void spmm_fused(const Csr& a, int epi, const double* X, int ldx, double* Y, int ldy, int m, const double* B, int ldb,
                 double* Z, int ldz, const double* dinv, double w) {
+  OMP_ROWS
   for (int i = 0; i < a.n; ++i)
     for (int j = 0; j < m; ++j) {
       double s = 0;
@@ -316,13 +366,22 @@ void segsum(double* out, const double* in, const int* ptr, const int* idx, int n
     out[e] = acc ? out[e] + s : s;
   }
 }
-void set(double* x, double v, int n) { for (int i = 0; i < n; ++i) x[i] = v; }
+void set(double* x, double v, int n) {
+  OMP_ROWS
+  for (int i = 0; i < n; ++i) x[i] = v;
+}
 void copy(double* y, const double* x, int n) { memmove(y, x, sizeof(double) * (size_t)n); }
-void axpy(double* y, double a, const double* x, int n) { for (int i = 0; i < n; ++i) y[i] += a * x[i]; }
+void axpy(double* y, double a, const double* x, int n) {
+  OMP_ROWS
+  for (int i = 0; i < n; ++i) y[i] += a * x[i];
+}
 void axpby(double* y, double a, const double* x, double b, int n) {
   for (int i = 0; i < n; ++i) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
 }
-void xmy(double* y, const double* x, const double* d, int n) { for (int i = 0; i < n; ++i) y[i] = x[i] * d[i]; }
+void xmy(double* y, const double* x, const double* d, int n) {
+  OMP_ROWS
+  for (int i = 0; i < n; ++i) y[i] = x[i] * d[i];
+}
 void axpy_dev(double* y, const double* a, double sign, const double* x, int n) {
   const double s = sign * a[0];
   for (int i = 0; i < n; ++i) y[i] += s * x[i];
@@ -366,6 +425,7 @@ void chunks_free(Chunks& c) {
 void seg_dot(const Chunks& c, const double* x, const double* y, double* out, int stride, int slot) {
   for (int s = 0; s < c.nsub; ++s) {
     double t = 0;
+    OMP_SUM(t)
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += x[i] * y[i];
     out[(int64_t)s * stride + slot] = t;
   }
@@ -386,6 +446,7 @@ void cg_start(const Chunks& c, double* sc, double* x, double* r, double* z, doub
 void seg_partial(const Chunks& c, const double* x, const double* y, int slot) {
   for (int s = 0; s < c.nsub; ++s) {
     double t = 0;
+    OMP_SUM(t)
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += x[i] * y[i];
     if (slot == 0) c.partial[s] = t;
     else c.partial[c.nsub + 2 * s + (slot - 1)] = t;
@@ -410,6 +471,7 @@ void dense_sym_apply(const Chunks& c, const double* inv, const int64_t* base, co
 void seg_pap(const Chunks& c, const double* p, const double* q) {
   for (int s = 0; s < c.nsub; ++s) {
     double t = 0;
+    OMP_SUM(t)
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) t += p[i] * q[i];
     c.partial[s] = t;  // hostsim keeps one partial per subdomain
   }
@@ -421,6 +483,7 @@ void cg_update(const Chunks& c, double* sc, int parity, double* x, double* r, do
     const double pap = c.partial[s];
     const double alpha = (t[6] != 0.0 && pap != 0.0) ? t[parity] / pap : 0.0;
     double nrz = 0, nrr = 0;
+    OMP_SUM2(nrz, nrr)
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
       x[i] += alpha * p[i];
       r[i] -= alpha * q[i];
@@ -438,8 +501,10 @@ void cg_direction(const Chunks& c, double* sc, int parity, double* p, const doub
     const double nrz = c.partial[c.nsub + 2 * s], nrr = c.partial[c.nsub + 2 * s + 1];
     const double rz = t[parity];
     const double beta = (t[6] != 0.0 && rz != 0.0) ? nrz / rz : 0.0;
-    if (t[6] != 0.0)
+    if (t[6] != 0.0) {
+      OMP_ROWS
       for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) p[i] = z[i] + beta * p[i];
+    }
     t[parity ^ 1] = nrz; t[3] = nrr; t[5] = beta;
     if (t[6] != 0.0 && nrr <= tol2 * t[7]) t[6] = 0.0;
   }
@@ -447,36 +512,35 @@ void cg_direction(const Chunks& c, double* sc, int parity, double* p, const doub
 
 void gram(const Chunks& c, const double* S, int lds, int p, const double* T, int ldt, int q, double* G) {
   for (int s = 0; s < c.nsub; ++s) {
-    double* g = G + (int64_t)s * p * q;
-    for (int e = 0; e < p * q; ++e) g[e] = 0;
-    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+    accumulate_rows(c.suboff[s], c.suboff[s + 1], p * q, G + (int64_t)s * p * q, [&](int i, double* g) {
       for (int a = 0; a < p; ++a) {
         const double sv = S[(int64_t)i * lds + a];
         if (sv == 0.0) continue;
         for (int b = 0; b < q; ++b) g[a * q + b] += sv * T[(int64_t)i * ldt + b];
       }
+    });
   }
 }
 void gram2(const Chunks& c, const double* S1, int lds1, int p1, const double* S2, int lds2, int p2, const double* T, int ldt,
            int q, double* G) {
   const int p = p1 + p2;
   for (int s = 0; s < c.nsub; ++s) {
-    double* g = G + (int64_t)s * p * q;
-    for (int e = 0; e < p * q; ++e) g[e] = 0;
-    for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i)
+    accumulate_rows(c.suboff[s], c.suboff[s + 1], p * q, G + (int64_t)s * p * q, [&](int i, double* g) {
       for (int a = 0; a < p; ++a) {
         const double sv = a < p1 ? S1[(int64_t)i * lds1 + a] : S2[(int64_t)i * lds2 + a - p1];
         if (sv == 0.0) continue;
         for (int b = 0; b < q; ++b) g[a * q + b] += sv * T[(int64_t)i * ldt + b];
       }
+    });
   }
 }
 void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C, int q, double* Y, int ldy,
                bool acc) {
-  std::vector<double> row(q);
   for (int s = 0; s < c.nsub; ++s) {
     const double* cs = C + (int64_t)s * p * q;
+    OMP_ROWS
     for (int i = c.suboff[s]; i < c.suboff[s + 1]; ++i) {
+      std::vector<double> row(q);
       for (int j = 0; j < q; ++j) row[j] = acc ? Y[(int64_t)i * ldy + j] : 0.0;
       for (int k = 0; k < p; ++k) {
         const double sv = S[(int64_t)i * lds + k];
@@ -490,6 +554,7 @@ void block_mul(const Chunks& c, const double* S, int lds, int p, const double* C
 void block_residual(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam, int m,
                     double* R, int ldr, double* nrm) {
   for (int s = 0; s < c.nsub; ++s)
+    OMP_ROWS
     for (int j = 0; j < m; ++j) {
       double t = 0;
       const double lj = lam[(int64_t)s * m + j];
@@ -504,6 +569,7 @@ void block_residual(const Chunks& c, const double* AX, int lda, const double* BX
 void block_residual_norms(const Chunks& c, const double* AX, int lda, const double* BX, int ldb, const double* lam,
                           int m, double* R, int ldr, const double* colmask, double* nrm3) {
   for (int s = 0; s < c.nsub; ++s)
+    OMP_ROWS
     for (int j = 0; j < m; ++j) {
       double tr = 0, ta = 0, tb = 0;
       const double lj = lam[(int64_t)s * m + j];
@@ -530,6 +596,7 @@ void block_colnorm(const Chunks& c, const double* X, int ldx, int m, double* nrm
     }
 }
 void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double b, int n, int m) {
+  OMP_ROWS
   for (int64_t i = 0; i < n; ++i)
     for (int j = 0; j < m; ++j) {
       const double xv = a * X[i * ldx + j];
@@ -538,6 +605,7 @@ void block_axpby(double* Y, int ldy, double a, const double* X, int ldx, double 
 }
 void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* d, double a, double b, int n,
                     int m) {
+  OMP_ROWS
   for (int64_t i = 0; i < n; ++i)
     for (int j = 0; j < m; ++j) {
       const double xv = a * d[i] * X[i * ldx + j];
@@ -546,6 +614,7 @@ void block_rowscale(double* Y, int ldy, const double* X, int ldx, const double* 
 }
 void jacobi_step(double* X, int ldx, const double* B, int ldb, const double* AX, const double* dinv, double w, int n,
                  int m, bool zero_guess) {
+  OMP_ROWS
   for (int64_t i = 0; i < n; ++i)
     for (int j = 0; j < m; ++j) {
       const double bv = B[i * ldb + j];
@@ -555,6 +624,7 @@ void jacobi_step(double* X, int ldx, const double* B, int ldb, const double* AX,
 }
 void cheb_update(double* r, const double* ad, double* d, double* z, int ldz, const double* dinv, double a, double b,
                  int n, int m) {
+  OMP_ROWS
   for (int64_t i = 0; i < n; ++i)
     for (int j = 0; j < m; ++j) {
       const int64_t e = i * m + j;

@@ -559,3 +559,31 @@ def test_library_threads_run_on_the_librarys_device(lib):
         assert lib.GeneoSetDevice(0) == 0
     assert lib.GeneoThreadDeviceCheck() == 0
 
+
+@pytest.mark.parametrize("per_row", [1, 3, 4, 6, 7, 8])
+def test_single_precision_companion_two_latency_form_is_bit_identical(lib, per_row):
+    """k_spmv_sell_lp, slices of <= 8 entries per row (every fine-level operator of the benchmark is 7 wide): all (col, val)
+    loads of the slice, then all gathers -- two dependent latencies instead of eight (lp_row_sum_fixed) -- with the products
+    summed in the order of the 4-step loop it replaces: bit-identical for every width 1..8, plain product and epilogues,
+    one and two column bases."""
+    from geneo4petsc_amd.pc import Spmv
+    n = 70000
+    rng = np.random.default_rng(per_row)
+    offs = sorted(set([0] + list(rng.choice(np.arange(-30000, 30000), size=per_row - 1, replace=False)))) if per_row > 1 else [0]
+    a = sp.diags([rng.random(n - abs(o)) - 0.5 for o in offs], offs, format="csr")
+    X, B, Z = rng.random(n) - 0.5, rng.random(n) - 0.5, rng.random(n) - 0.5
+    dinv, w = rng.random(n) + 0.5, 0.61
+    h = Spmv(a, lib)
+    res = []
+    for on in (1, 0):
+        assert lib.GeneoSetKernelVariant(b"lp_fixed", on) == 0
+        out = [h.fused_single(0, X=X)[0], h.fused_single(1, X=X, B=B)[0], h.fused_single(2, X=X, Z=Z)[0],
+               h.fused_single(3, X=X, B=B, dinv=dinv, w=w)[0], h.fused_single(5, X=X, B=B, Z=Z, dinv=dinv, w=w)[0]]
+        out += list(h.fused_single(4, B=B, dinv=dinv, w=w))
+        res.append(out)
+    lib.GeneoSetKernelVariant(b"lp_fixed", 1)
+    for y1, y0 in zip(*res):
+        np.testing.assert_array_equal(y1, y0)
+    a32 = a.copy()
+    a32.data = a32.data.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(res[0][0], a32 @ X, rtol=1e-12, atol=1e-13)
