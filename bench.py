@@ -151,7 +151,11 @@ def build_problem(args, rank, size):
     n, parts, sub_rank, spg = workload(args, size)
     nb = len(sub_rank)
     my = [s for s in range(nb) if sub_rank[s] == rank]
-    doms = [decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True) for s in my]
+    # the rank's subdomains side by side (the generator and the decomposition are C++ calls and numpy passes that release
+    # the interpreter lock: 368^3 on one rank, eight 6.5 M-row subdomains: 33 s one after the other)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(my)))) as ex:
+        doms = list(ex.map(lambda s: decomp.decompose_grid_domain(n, 3, parts, args.overlap, s, native=True), my))
     plan = decomp.grid_rank_plan(n, 3, parts, args.overlap, sub_rank, rank, size, doms)
     # b = A (1, 2, ..., N) (driver:820-831) on the owned rows
     npart_of = lambda gid: ((gid % n) * parts[0]) // n + parts[0] * ((((gid // n) % n) * parts[1]) // n
@@ -231,15 +235,20 @@ def cpu_baseline(args, doms, lib):
     rp, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
     x = np.random.default_rng(0).random(a.shape[0])
     y = np.zeros(a.shape[0])
-    args_c = (C.c_int(a.shape[0]), rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
-              val.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
-    olib.oracle_csr_spmv(*args_c)
+    # copies whose pages are first touched by the threads that read them (NUMA placement: arrays filled by this one
+    # Python thread sit on one memory node of the two-socket host)
+    olib.oracle_spmv_place.restype = C.c_void_p
+    hp = C.c_void_p(olib.oracle_spmv_place(C.c_int(a.shape[0]), rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                           val.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p)))
+    olib.oracle_spmv_placed(hp)
     reps = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 5.0 and reps < 400:
-        olib.oracle_csr_spmv(*args_c)
+        olib.oracle_spmv_placed(hp)
         reps += 1
     dt = (time.perf_counter() - t0) / max(1, reps)
+    olib.oracle_spmv_result(hp, y.ctypes.data_as(C.c_void_p))
+    olib.oracle_spmv_free(hp)
     nbytes = a.nnz * 12 + (a.shape[0] + 1) * 4 + a.shape[0] * 16
     out["value"] = nbytes / dt / 1e9
     out["cores"] = int(olib.oracle_num_threads())
@@ -247,9 +256,11 @@ def cpu_baseline(args, doms, lib):
         a.shape[0], a.nnz, len(take), len(doms), reps)
     # (2) the SAME ALGORITHM compiled for the host cores: the library's own orchestration (LOBPCG with
     #     the AMG V-cycle, batched AMG-PCG local solves, E, PCG) over the OpenMP build of the test backend
-    #     (tests/hostsim: -O3 -mavx2 -mfma -fopenmp), at a REAL size: BASELINE configs[1], 126^3 = 2.0 M DoF in 8 subdomains
-    #     with the bench's own options -- the whole set-up + solve where the box has >= 64 cores, otherwise ONE of its eight
-    #     subdomains (67^3-class block, 286 k rows) as a stand-alone problem.  Bench infrastructure: never a product backend.
+    #     (tests/hostsim: -O3 -mavx2 -mfma -fopenmp), at a REAL size: ONE of the eight subdomains of BASELINE configs[1]
+    #     (126^3 = 2.0 M DoF, 8 subdomains: a 67^3-class block of 286 k rows) with the bench's own options as a stand-alone
+    #     problem -- its whole set-up and 25 PCG iterations on its local operator (the bounded sample of the contract; the
+    #     whole 126^3 problem, GENEO_BENCH_CPU_WHOLE=1, took 118 + 48 s on the MI355X host).  Bench infrastructure: never a
+    #     product backend.
     try:
         out["geneo_sample"] = cpu_geneo_sample(args)
     except Exception as e:
@@ -308,14 +319,21 @@ def cpu_geneo_sample(args):
     import build as hs_build
     from geneo4petsc_amd import _lib as L, decomp
     from geneo4petsc_amd.pc import GenEOPC
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # 64 threads: the row loops of a 286 k-row subdomain stop scaling there (MI355X host, 256 hardware threads: the whole
+    # 126^3 problem took 118 + 48 s on all 256, OpenMP region overheads on the small coarse levels included)
+    cores = max(1, min(64, avail))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "spread")
+    try:      # libgomp is already initialised (the SpMV leg): the environment is read only once
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(cores))
+    except OSError:
+        pass
     hlib = L.bind(hs_build.build_omp())
     assert hlib.GeneoBackendName() == b"host-openmp"
     n, parts = 126, (2, 2, 2)
     argv = geneo_argv(args)
-    whole = cores >= 64
+    whole = bool(os.environ.get("GENEO_BENCH_CPU_WHOLE"))      # the whole 126^3 problem: minutes; default: one subdomain of it
     t0 = time.perf_counter()
     pc = GenEOPC(hlib)
     if whole:

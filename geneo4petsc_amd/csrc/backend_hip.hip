@@ -81,12 +81,19 @@ static bool g_no_mfma = false;
 static bool g_spgemm_fill_scan = getenv("GENEO_SPGEMM_SCAN_FILL") != nullptr;   // the owner-computes numeric pass of round 2
 static bool g_gram_flat = getenv("GENEO_GRAM_NO_FLAT") == nullptr;               // 16-byte streaming form of LOBPCG's Grams
 static bool g_init = false;
+// set_variant("lp_fixed", 0) / GENEO_LP_FIXED=0: the 4-step loop for every slice of k_spmv_sell_lp instead of its two-latency
+// forms (validation, A/B)
+__device__ int g_lp_no_fixed = 0;
 
 static void lazy_init() {
   if (g_init) return;
   g_init = true;
   const char* e = getenv("GENEO_NO_MFMA");
   g_no_mfma = (e && e[0] == '1');
+  if (const char* f = getenv("GENEO_LP_FIXED")) {
+    const int off = atoi(f) ? 0 : 1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lp_no_fixed), &off, sizeof(int));
+  }
 }
 
 const char* name() { return "hip-gfx950"; }
@@ -2178,7 +2185,6 @@ bool csr_make_lp(Csr& a, const Csr* index_owner) {
 // run time IS that chain (0.46-0.54 of the HBM peak while the FP64 SpMV on the same pattern reaches
 // 0.72).  The products are summed exactly as that loop sums them (KW / 4 rounds into four accumulators, the remainder
 // into the first): results are bit-identical.
-__device__ int g_lp_no_fixed = 0;       // set_variant("lp_fixed", 0): the 4-step loop for every slice (validation, A/B)
 template <int KW, int EPI, typename COLT, bool NT>
 __device__ __forceinline__ double lp_row_sum_fixed(const COLT* __restrict__ col, const float* __restrict__ val, int64_t e0,
                                                    const int4 cb, const double* __restrict__ xin,
@@ -2201,6 +2207,43 @@ __device__ __forceinline__ double lp_row_sum_fixed(const COLT* __restrict__ col,
     for (int u = 0; u < 4; ++u) acc[u] += v[4 * g + u] * xv[4 * g + u];
 #pragma unroll
   for (int k = 4 * NG; k < KW; ++k) acc[0] += v[k] * xv[k];
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// The same for slices of 9 .. 16 entries per row (the post-smoothing matrices M = P - w D^-1 A P of the V-cycle: 12 wide on
+// the 7-point problem, three rounds of the 4-step loop = six dependent latencies): sixteen predicated steps (wd is
+// wave-uniform: scalar branches, lanes past the width load nothing), all loads, then all gathers, then the products in the
+// loop's order -- entry u < 4 (wd / 4) goes to accumulator u mod 4, the remainder to the first, in increasing u.
+// (The same sequence for the workgroup-per-slice kernel -- each of its four waves owning every fourth entry of a row -- was
+//  measured on one box, three runs each at 6.5 M rows: companion passes 82 us with the wave-per-slice forms alone, 92 us with
+//  both, 92 us with neither (profiles/r04_lp_two_latency_ab.log): it costs what the narrow forms gain, and is not built.)
+template <int EPI, typename COLT, bool NT>
+__device__ __forceinline__ double lp_row_sum_p16(const COLT* __restrict__ col, const float* __restrict__ val, int64_t e0,
+                                                 int wd, const int4 cb, const double* __restrict__ xin,
+                                                 const double* __restrict__ cs) {
+  int c[16];
+  double v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    c[u] = cb.x;
+    v[u] = 0.0;
+    if (u < wd) {
+      c[u] = (u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e0 + 64 * u) : col[e0 + 64 * u]);
+      v[u] = (double)(NT ? __builtin_nontemporal_load(val + e0 + 64 * u) : val[e0 + 64 * u]);
+    }
+  }
+  double xv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    xv[u] = 0.0;
+    if (u < wd) xv[u] = (EPI == EPI_PRE && cs) ? xin[c[u]] * cs[c[u]] : xin[c[u]];
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int ng4 = (wd >> 2) << 2;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (u < ng4) acc[u & 3] += v[u] * xv[u];
+    else if (u < wd) acc[0] += v[u] * xv[u];
+  }
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 // WPS = 1: one wave per slice (four slices per workgroup), WPS = 4: one workgroup per slice (wide slices), as the FP64
@@ -2250,8 +2293,11 @@ __global__ __launch_bounds__(256) void k_spmv_sell_lp(const int64_t* __restrict_
   int k = (WPS == 1 ? 0 : wv);            // entry index of e within its row
   const int wd = (int)((e1 - a) >> 6);    // entries per row of this slice (wave-uniform)
   double fixed_sum = 0.0;
-  const bool fixed = (WPS == 1 && wd >= 1 && wd <= 8 && !g_lp_no_fixed);
-  if (fixed) {
+  const bool fixed = (WPS == 1 && wd >= 1 && wd <= 16 && !g_lp_no_fixed);
+  if (fixed && wd > 8) {
+    fixed_sum = lp_row_sum_p16<EPI, COLT, NT>(col, val, e, wd, cb, xin, cs);
+    e = e1;
+  } else if (fixed) {
     switch (wd) {
       case 1: fixed_sum = lp_row_sum_fixed<1, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;
       case 2: fixed_sum = lp_row_sum_fixed<2, EPI, COLT, NT>(col, val, e, cb, xin, cs); break;

@@ -26,7 +26,10 @@ def free_port():
 
 @pytest.mark.parametrize("lvl,ksp,parts,extra", [
     ("ASM,1", "cg", (2, 2, 2), []), ("RAS,H1", "gmres", (2, 2, 2), []),
-    ("SRAS,1", "cg", (2, 1, 1), []),        # ONE subdomain per rank: the layout of bench.py --gpus N (config 3)
+    ("SRAS,1", "cg", (2, 1, 1), []),        # ONE subdomain per rank: the layout of bench.py --gpus 8 (config 3)
+    # bench.py --scaling strong at N = 2: four of the eight subdomains per rank, eigensolved group by group under the
+    # device-memory budget (one subdomain per group here), the next group prepared on a helper thread
+    ("SRAS,1", "cg", (2, 2, 2), ["-geneo_eig_group_rows", "1"]),
     ("SORAS,2", "cg", (4, 2, 1), ["-geneo_tau", "0.02", "-geneo_gamma", "1.05", "-geneo_cut", "12", "-geneo_optim", "0.5"])])
 def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     out = str(tmp_path / "res.npz")
@@ -43,7 +46,8 @@ def test_two_ranks_match_serial_oracle(tmp_path, lvl, ksp, parts, extra):
     mesh, dec, a, b = cases.grid_case(12, 3, parts, 1)
     np.testing.assert_allclose(got["b"], b, rtol=1e-13)
     argv = ["-geneo_lvl", lvl, "-geneo_tau", "0.2", "-geneo_cut", "8", "-ksp_type", ksp, "-els2_eps_tol", "1e-10",
-            "-ksp_rtol", "1e-6" if ksp == "cg" else "1e-8"] + extra     # cases.Tight: CG counts at 1e-6
+            "-ksp_rtol", "1e-6" if ksp == "cg" else "1e-8"] + \
+        [e for i, e in enumerate(extra) if "-geneo_eig_group_rows" not in (e, extra[i - 1] if i else "")]   # cases.Tight: CG counts at 1e-6
     orc = cases.oracle_for(mesh, dec, argv, b)
     kspname, kw = cases.ksp_args(argv)
     res = go.solve(orc, b, kspname, **kw)

@@ -126,6 +126,31 @@ def test_solution_1e10(lib):
     assert np.linalg.norm(x - exact) <= 1e-10 * np.linalg.norm(exact)
 
 
+@pytest.mark.parametrize("lvl,ksp", [("SRAS,1", "cg"), ("RAS,1", "gmres")])
+def test_converged_solution_matches_the_oracles_to_1e10_at_the_bench_options(lib, lvl, ksp):
+    """north_star: "eigenvalues and solution within 1e-10 relative".  The bench's own option set (overlap 2, -geneo_cut 20,
+    tau 0.35, AMG inside the local solves and LOBPCG) on 24^3 in 8 subdomains with both Krylov loops driven to
+    convergence (-ksp_rtol 1e-13): the library's solution against the ORACLE's (exact LU, exact eigenpairs) -- two
+    converged solves of the same system -- and against the analytic one (1, 2, .., N), all within 1e-10 relative."""
+    import oracle.geneo_oracle as go
+    argv = cases.bench_argv(["-geneo_lvl", lvl, "-ksp_type", ksp, "-ksp_rtol", "1e-13", "-ksp_gmres_restart", "200",
+                             "-els2_eps_tol", "1e-10", "-dls1_ksp_rtol", "1e-12"])
+    mesh, dec, a, b = cases.grid_case(24, 3, (2, 2, 2), cases.BENCH_OVERLAP)
+    pc = cases.run_pc(lib, mesh, dec, argv, b)
+    x, its, rnorm, reason = pc.solve(b)
+    assert reason.startswith("KSP_CONVERGED"), reason
+    orc = cases.oracle_for(mesh, dec, argv, b)
+    kspname, kw = cases.ksp_args(argv)
+    res = go.solve(orc, b, kspname, **kw)
+    exact = np.arange(1.0, mesh.nbNode + 1.0)
+    assert np.linalg.norm(res.x - exact) <= 1e-10 * np.linalg.norm(exact)
+    assert np.linalg.norm(x - exact) <= 1e-10 * np.linalg.norm(exact)
+    assert np.linalg.norm(x - res.x) <= 1e-10 * np.linalg.norm(res.x)
+    for s in range(8):
+        np.testing.assert_allclose(np.sort(pc.eigenvalues(s)), np.sort(orc.eigvals[s]), rtol=1e-10, atol=1e-13)
+    pc.destroy()
+
+
 @pytest.mark.parametrize("rec", dc.geneo_refs(),
                          ids=lambda r: r["file"][:-4])
 def test_dummy_goldens_on_gpu(lib, rec):

@@ -560,12 +560,12 @@ def test_library_threads_run_on_the_librarys_device(lib):
     assert lib.GeneoThreadDeviceCheck() == 0
 
 
-@pytest.mark.parametrize("per_row", [1, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("per_row", [1, 3, 4, 6, 7, 8, 9, 11, 12, 13, 15])
 def test_single_precision_companion_two_latency_form_is_bit_identical(lib, per_row):
-    """k_spmv_sell_lp, slices of <= 8 entries per row (every fine-level operator of the benchmark is 7 wide): all (col, val)
-    loads of the slice, then all gathers -- two dependent latencies instead of eight (lp_row_sum_fixed) -- with the products
-    summed in the order of the 4-step loop it replaces: bit-identical for every width 1..8, plain product and epilogues,
-    one and two column bases."""
+    """k_spmv_sell_lp, slices of <= 16 entries per row (the fine-level operators of the benchmark are 7 wide, the
+    post-smoothing matrices of the V-cycle 12): all (col, val) loads of the slice, then all gathers -- two dependent
+    latencies instead of up to eight (lp_row_sum_fixed, lp_row_sum_p16) -- with the products summed in the order of the
+    4-step loop they replace: bit-identical for every width, plain product and epilogues, one and two column bases."""
     from geneo4petsc_amd.pc import Spmv
     n = 70000
     rng = np.random.default_rng(per_row)
