@@ -1729,6 +1729,34 @@ __device__ __forceinline__ int4 lp_base_of(const int* __restrict__ base, int s) 
 // non-temporal so that it does not displace x from the XCD's L2.
 // COLT = unsigned short: the columns are read as 16-bit offsets from the slice's lowest column (cbase[s]; the index
 // arrays of the single-precision companion, shared) -- 10 bytes per entry instead of 12 with the FP64 values untouched.
+// Slices of KW <= 8 entries per row with every (col, val) load in front of the first gather and all gathers in flight
+// together -- two dependent latencies instead of up to eight -- and the products summed in the order of the 4-step loop of
+// k_spmv_sell<4, ..> below (KW / 4 rounds into four accumulators, the remainder into the first, then acc0 + acc1 + acc2 +
+// acc3): bit-identical to it.  (k_spmv_sell_p8 further down is the round-3 form of the same idea with another summation
+// order; the single-precision companion kernels have theirs in lp_row_sum_fixed.)
+template <int KW, bool NT, typename COLT>
+__device__ __forceinline__ double spmv_row_sum_fixed(const COLT* __restrict__ col, const double* __restrict__ val, int64_t e0,
+                                                     const int4 cb, const double* __restrict__ x) {
+  int c[KW];
+  double v[KW];
+#pragma unroll
+  for (int u = 0; u < KW; ++u) {
+    c[u] = (u < cb.z ? cb.x : cb.y) + (int)(NT ? __builtin_nontemporal_load(col + e0 + 64 * u) : col[e0 + 64 * u]);
+    v[u] = NT ? __builtin_nontemporal_load(val + e0 + 64 * u) : val[e0 + 64 * u];
+  }
+  double xv[KW];
+#pragma unroll
+  for (int u = 0; u < KW; ++u) xv[u] = x[c[u]];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NG = KW / 4;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += v[4 * g + u] * xv[4 * g + u];
+#pragma unroll
+  for (int k = 4 * NG; k < KW; ++k) acc[0] += v[k] * xv[k];
+  return ((acc[0] + acc[1]) + acc[2]) + acc[3];
+}
 template <int UNR, bool NT, typename COLT = int>
 __global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ sl_ptr, int nslice, int n,
                                                    const COLT* __restrict__ col, const double* __restrict__ val,
@@ -1741,6 +1769,25 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const int64_t* __restrict__ s
   const int l = threadIdx.x & 63;
   const int64_t a = sl_ptr[s], b = sl_ptr[s + 1];
   const int4 cb = lp_base_of(cbase, s);       // {b0, b1, ks}: entries k < ks count from b0, the others from b1
+  if (UNR == 4 && !g_lp_no_fixed) {           // narrow slice: the two-latency form (same sums, same order)
+    const int wd = (int)((b - a) >> 6);
+    if (wd >= 1 && wd <= 8) {
+      double fs;
+      switch (wd) {
+        case 1: fs = spmv_row_sum_fixed<1, NT, COLT>(col, val, a + l, cb, x); break;
+        case 2: fs = spmv_row_sum_fixed<2, NT, COLT>(col, val, a + l, cb, x); break;
+        case 3: fs = spmv_row_sum_fixed<3, NT, COLT>(col, val, a + l, cb, x); break;
+        case 4: fs = spmv_row_sum_fixed<4, NT, COLT>(col, val, a + l, cb, x); break;
+        case 5: fs = spmv_row_sum_fixed<5, NT, COLT>(col, val, a + l, cb, x); break;
+        case 6: fs = spmv_row_sum_fixed<6, NT, COLT>(col, val, a + l, cb, x); break;
+        case 7: fs = spmv_row_sum_fixed<7, NT, COLT>(col, val, a + l, cb, x); break;
+        default: fs = spmv_row_sum_fixed<8, NT, COLT>(col, val, a + l, cb, x); break;
+      }
+      const int rr = 64 * s + l;
+      if (rr < n) y[rr] = fs;
+      return;
+    }
+  }
   double acc[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) acc[u] = 0.0;

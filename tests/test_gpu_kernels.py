@@ -587,3 +587,27 @@ def test_single_precision_companion_two_latency_form_is_bit_identical(lib, per_r
     a32 = a.copy()
     a32.data = a32.data.astype(np.float32).astype(np.float64)
     np.testing.assert_allclose(res[0][0], a32 @ X, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("per_row", [1, 2, 5, 7, 8])
+@pytest.mark.parametrize("companion", [False, True])
+def test_fp64_spmv_two_latency_form_is_bit_identical(lib, per_row, companion):
+    """k_spmv_sell<4, ..> on slices of <= 8 entries per row (spmv_row_sum_fixed: all loads, then all gathers, the products
+    summed in the 4-step loop's order): the same bits as the loop it replaces, with 32-bit columns and with the companion's
+    16-bit column offsets (the form the inner PCG of the local solves launches)."""
+    from geneo4petsc_amd.pc import Spmv
+    n = 300000                           # large enough for the non-temporal / 16-bit-column policy of the solver
+    rng = np.random.default_rng(40 + per_row)
+    offs = sorted(set([0] + list(rng.choice(np.arange(-20000, 20000), size=per_row - 1, replace=False)))) if per_row > 1 else [0]
+    a = sp.diags([rng.random(n - abs(o)) - 0.5 for o in offs], offs, format="csr")
+    x = rng.random(n) - 0.5
+    h = Spmv(a, lib)
+    if companion:
+        h.fused_single(0, X=x)           # builds the companion: the FP64 SpMV then reads its 16-bit column offsets
+    out = []
+    for on in (1, 0):
+        assert lib.GeneoSetKernelVariant(b"lp_fixed", on) == 0
+        out.append(h.apply(x))
+    lib.GeneoSetKernelVariant(b"lp_fixed", 1)
+    np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_allclose(out[0], a @ x, rtol=1e-12, atol=1e-13)
