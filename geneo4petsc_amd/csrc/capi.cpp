@@ -165,6 +165,7 @@ const char* usageGenEO_c(void) {
          "  -dls1_amg_precision single|double   storage of the matrices its V-cycle reads (arithmetic and vectors: double)\n"
          "  -dls1_amg_strength T / -els2_amg_strength T   aggregation from level 1 on ties |a_ij| >= T 0.5^l sqrt(a_ii a_jj) only\n"
          "  -amg_coarse_size / -amg_smooth_degree / -amg_smooth_ratio / -amg_max_levels\n"
+         "  -dls1_amg_smooth_ratio R / -els2_amg_smooth_ratio R   the smoothing interval [rho / R, 1.1 rho] per hierarchy\n"
          "  -ksp_type cg|gmres -ksp_rtol -ksp_atol -ksp_max_it -ksp_gmres_restart\n\n";
 }
 

@@ -169,6 +169,8 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   if (key == "-amg_coarse_size") return integer(o.amg_coarse_size);
   if (key == "-amg_smooth_degree") return integer(o.amg_smooth_degree);
   if (key == "-amg_smooth_ratio") return dbl(o.amg_smooth_ratio);
+  if (key == "-dls1_amg_smooth_ratio") return dbl(o.dls1_amg_smooth_ratio);
+  if (key == "-els2_amg_smooth_ratio") return dbl(o.els2_amg_smooth_ratio);
   if (key == "-amg_max_levels") return integer(o.amg_max_levels);
   if (key == "-ksp_type") {
     if (value != "cg" && value != "gmres") return "unsupported -ksp_type " + value;
@@ -708,8 +710,10 @@ int PC::setup_prepare() {
   const AmgParams ap = amg_params(opt);
   AmgParams ap1h = ap;                      // the level-1 hierarchy (local solves): its own aggregation strength
   ap1h.strength = opt.dls1_amg_strength;
+  if (opt.dls1_amg_smooth_ratio > 0.0) ap1h.smooth_ratio = opt.dls1_amg_smooth_ratio;
   AmgParams apN = ap;                       // the A_Neu hierarchy (LOBPCG preconditioner)
   apN.strength = opt.els2_amg_strength;
+  if (opt.els2_amg_smooth_ratio > 0.0) apN.smooth_ratio = opt.els2_amg_smooth_ratio;
   // The host part of the fine level of both hierarchies (Jacobi diagonal, Gershgorin bound, aggregates) needs nothing
   // but the host matrices: it runs on its own threads from here on, behind the uploads and the diagonals (with ONE
   // 6.5 M-row subdomain per GPU it is 0.08-0.1 s per hierarchy of a single thread).

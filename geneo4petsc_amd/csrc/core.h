@@ -60,6 +60,14 @@ struct Options {
   std::string dls1_pc = "amg", els2_pc = "amg";
   int amg_coarse_size = 600, amg_smooth_degree = 1, amg_max_levels = 10;
   double amg_smooth_ratio = 4.0;
+  // the same per hierarchy (0: the common -amg_smooth_ratio): -dls1_amg_smooth_ratio for the level-1 hierarchy of the local
+  // solves, -els2_amg_smooth_ratio for LOBPCG's A_Neu hierarchy
+  // Local solves: 12 -- the damped-Jacobi weight 1 / (0.55 rho (1 + 1 / ratio)) grows from 1.45 / rho (ratio 4) to 1.68 / rho
+  // against a Gershgorin bound that overestimates rho(D^-1 A): one rank of 368^3, 496 -> 440 inner iterations, solve 0.391 ->
+  // 0.349 s, flat from 12 up (profiles/r04_inner_solver_sweep_rank_of_8.log).  The inner PCG runs to -dls1_ksp_rtol whatever
+  // its preconditioner, so the outer iteration is unchanged.  LOBPCG's hierarchy keeps 4: its V-cycle is also the ruler of
+  // the convergence test at -els2_eps_tol (8: 19 -> 18 iterations, and a different ruler).
+  double dls1_amg_smooth_ratio = 12.0, els2_amg_smooth_ratio = 0.0;
   // -dls1_amg_strength / -els2_amg_strength (AmgParams::strength).  Local solves: 0.04 (126^3: 26 -> 18 inner iterations per
   // solve, same outer counts).  LOBPCG's hierarchy keeps every connection: its V-cycle is also the ruler of the convergence
   // test at -els2_eps_tol, and a different ruler moves the outer iteration count at the loose tolerance of the benchmark
