@@ -1113,6 +1113,8 @@ void PC::local_solve(double* wL) {
     else cg_graphs[len] = g;
     return g;
   };
+  static const bool dbg_dls1 = getenv("GENEO_DEBUG_DLS1") != nullptr;   // per solve: the chunk boundary each subdomain froze at
+  std::vector<int> conv_at(dbg_dls1 ? ns : 0, -1);
   // runs `len` iterations, then reads the per-subdomain flags back
   auto run = [&](int len) {
     void* g = graph_for(len);
@@ -1125,16 +1127,26 @@ void PC::local_solve(double* wL) {
     it += len;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
     done = true;
-    for (int s = 0; s < ns; ++s)
+    for (int s = 0; s < ns; ++s) {
       if (sc[(size_t)s * 8 + 6] != 0.0) done = false;
+      else if (dbg_dls1 && conv_at[s] < 0) conv_at[s] = it;
+    }
   };
   // Every chunk boundary is a host round trip (flags D2H + graph launch: ~0.17 ms against 0.3 ms per iteration).  The
   // solves of one set-up need almost the same number of iterations (126^3: 17 to 20), so after the first solve the
   // others start with ONE long chunk just below that number and finish in chunks of 2.
   static const bool adaptive = !getenv("GENEO_DLS1_FIXED_CHUNKS");
   if (use_amg && adaptive && cg_long_len >= 8 && check % 2 == 0) {
-    run(cg_long_len);
+    const int first = cg_long_len;
+    run(first);
     while (!done && it < opt.dls1_max_it) run(2);
+    // The long chunk follows what the solves need.  The first solve of a set-up (the one the length was taken from) is the
+    // hardest -- 368^3: 24 iterations, the others 16 -- and a chunk that ends after convergence is iterations nobody asked
+    // for: at 5.6 ms each on 52 M rows, two of them per solve are 10 % of the solve.  Converged inside the long chunk: probe
+    // a chunk two shorter next time; two or more short chunks behind it: two longer.  Steady state: the long chunk plus one
+    // short one, i.e. the iterations needed rounded up to even.
+    if (it == first && first > 8) cg_long_len = first - 2;
+    else if (it >= first + 4) cg_long_len = first + 2;
   } else {
     while (!done && it < opt.dls1_max_it) run(check);
     if (use_amg && adaptive && done && cg_long_len == 0 && check % 2 == 0) {
@@ -1144,6 +1156,11 @@ void PC::local_solve(double* wL) {
   }
   info.dls1_iterations += it;
   info.dls1_solves += 1;
+  if (dbg_dls1) {
+    fprintf(stderr, "[dls1] solve %lld: %d iterations (first chunk %d), subdomains frozen at", info.dls1_solves, it, cg_long_len);
+    for (int s = 0; s < ns; ++s) fprintf(stderr, " %d", conv_at[s]);
+    fprintf(stderr, "\n");
+  }
   if (!done) throw std::runtime_error("GenEO - solve KO: dls1 (KSP_DIVERGED_ITS)");
   if (opt.lvl1SRAS) bk::xmy(wL, x, d_D, nL);
   else bk::copy(wL, x, nL);
