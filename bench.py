@@ -66,7 +66,7 @@ def build_parser():
                     help="--scaling weak: grid points per side per GPU; 0 = 126 at N = 1 (2.0 M DoF), 184 at N > 1")
     ap.add_argument("--subdomains-per-gpu", type=int, default=0, choices=(0, 1, 2, 4, 8),
                     help="--scaling weak: 0 = 8 at N = 1, 1 at N > 1.  --scaling strong: always 8 / N")
-    ap.add_argument("--n", type=int, default=0, help="global grid side (--scaling strong: default 368)")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=0, help="global grid side (--scaling strong: default 368)")
     ap.add_argument("--overlap", type=int, default=2)
     ap.add_argument("--lvl", default="SRAS,1", help="-geneo_lvl; SRAS keeps the RAS weighting and a CG-legal (symmetric) PC")
     ap.add_argument("--tau", type=float, default=0.35)
@@ -520,8 +520,10 @@ def spawn(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # (torchrun's own parser would read a bare `--n` behind the script path as an abbreviation of its --nnodes / --nproc...)
+    fwd = ["--grid" if a == "--n" else a for a in sys.argv[1:]]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + fwd
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -762,7 +764,10 @@ def main():
             for k in kernels:
                 key = k["kernel"].split(" ")[0]
                 hits = [v for name, v in prof.items() if isinstance(v, dict) and name.startswith(key) and "traffic_over_algorithmic" in v]
-                if hits and abs(hits[0].get("rows", info_rows) - info_rows) <= 0.01 * info_rows:
+                # the ratio of a class is a property of the matrix the XCDs walk: applied when the profile was measured on
+                # this rank's rows or on ONE of its (equal) subdomains
+                prow = hits[0].get("rows", info_rows) if hits else 0
+                if hits and (abs(prow - info_rows) <= 0.01 * info_rows or abs(prow - info_rows / max(1, len(doms))) <= 0.01 * prow):
                     k["traffic_over_algorithmic"] = hits[0]["traffic_over_algorithmic"]
                     k["traffic"] = hits[0]["traffic_over_algorithmic"] * k["algorithmic_bytes_per_launch"]
         except Exception as e:

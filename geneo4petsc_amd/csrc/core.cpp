@@ -631,8 +631,79 @@ int PC::finish_amg1() {
 
 // ------------------------------------------------------------------------------------ setup
 int PC::setup(const double* b_dev) {
-  if (int rc = setup_prepare()) return rc;
-  return setup_finish(b_dev);
+  // Memory-bounded set-up (several groups of eigensolves): this PC's own device preparation -- 8.8 GB of fine matrices
+  // through the pinned staging buffers, their sliced layouts and companions, the diagonals, the start of the level-1
+  // hierarchy: 0.4 s at 368^3 -- runs on a helper thread and side stream WHILE this thread runs the grouped eigensolves,
+  // which need none of it.  The helper first makes the host copies it needs of the subdomain matrices (block-diagonal
+  // forms, partition of unity) and then releases the subdomains (`subs_released`) for eigen_grouped, which moves their
+  // matrices in and out of its temporary PCs.  GENEO_SETUP_NO_OVERLAP=1: one after the other.
+  bool overlap = false;
+  if (!eig_only && subs.size() >= 2 && opt.lvl2 == 1 && !opt.check && opt.els2_pc == "amg" && !getenv("GENEO_SETUP_NO_OVERLAP")) {
+    int nmax = 0;
+    for (auto& s : subs) nmax = std::max(nmax, (int)s.l2g.size());
+    overlap = nmax > 192 && validate_options(opt).empty() && N > 0 && plan_eig_groups().size() > 2;
+  }
+  if (!overlap) {
+    if (int rc = setup_prepare()) return rc;
+    return setup_finish(b_dev);
+  }
+  const auto t0 = clk::now();
+  std::promise<bool> released;
+  std::future<bool> subs_free = released.get_future();
+  subs_released = &released;
+  int rc_prep = 1;
+  std::string err_prep;
+  std::thread helper([&]() {
+    try {
+      bk::side_stream_begin();
+      rc_prep = setup_prepare();
+      if (rc_prep) err_prep = last_error;
+      bk::side_stream_end();
+    } catch (std::exception& e) {
+      bk::side_stream_end();
+      err_prep = e.what();
+    }
+    if (subs_released) {      // an early return: nothing was released
+      subs_released = nullptr;
+      released.set_value(false);
+    }
+  });
+  int rc_eig = 0;
+  std::string err_eig;
+  if (subs_free.get()) {      // host copies made: the subdomains are this thread's now
+    try {
+      rc_eig = setup_level2_eigen();
+      if (rc_eig) err_eig = last_error;
+    } catch (std::exception& e) {
+      rc_eig = 1;
+      err_eig = e.what();
+    }
+    eig_early = (rc_eig == 0);
+  }
+  helper.join();
+  if (rc_prep) { eig_early = false; is_setup = false; return fail(err_prep.empty() ? "GenEO preconditioner: set-up failed" : err_prep); }
+  if (rc_eig) { eig_early = false; is_setup = false; return fail(err_eig); }
+  const int rc = setup_finish(b_dev);
+  eig_early = false;
+  info.setupTime = secs(t0, clk::now()) - release_secs;     // wall clock of both threads, the release of the previous set-up excluded
+  return rc;
+}
+
+// D = 1 / mult on the host (geneo.cpp:965-1000), into h_Dscratch: kept from one set-up to the next (no page faults, no
+// zero fill); one pass over the local space, whatever the subdomains
+void PC::fill_partition_of_unity() {
+  const int ns = (int)subs.size();
+  std::vector<double>& D = h_Dscratch;
+  if ((int)D.size() != std::max(1, nL)) D.resize(std::max(1, nL));
+  parallel_ranges((int64_t)nL, [&](int64_t i0, int64_t i1) {
+    int s = (int)(std::upper_bound(suboff.begin(), suboff.end(), (int)i0) - suboff.begin()) - 1;
+    for (int64_t i = i0; i < i1;) {
+      while (s + 1 < ns && i >= suboff[s + 1]) ++s;
+      const auto& mult = subs[s].mult;
+      const int64_t e = std::min<int64_t>(i1, suboff[s + 1]);
+      for (; i < e; ++i) D[i] = 1.0 / (double)mult[i - suboff[s]];
+    }
+  });
 }
 
 // First half of the set-up: layout, matrices on the device, diagonals, the A_Neu hierarchy (and the start of the level-1
@@ -643,7 +714,8 @@ int PC::setup_prepare() {
   // allocated; the clock of setupTime starts after that release
   const auto t_rel = clk::now();
   free_all();
-  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] release of the previous set-up (outside setupTime) %.4f s\n", secs(t_rel, clk::now()));
+  release_secs = secs(t_rel, clk::now());
+  if (getenv("GENEO_DEBUG")) fprintf(stderr, "[setup] release of the previous set-up (outside setupTime) %.4f s\n", release_secs);
   info = Info();
   if (!eig_only) (void)amg_null_pivots_take();     // (a group of eigen_grouped counts into its owner's total)
   auto t0 = clk::now();
@@ -684,10 +756,32 @@ int PC::setup_prepare() {
   // local solves then reads 10 bytes per entry instead of 12, the level-1 hierarchy borrows the companion) by its own
   // thread on a side stream, next to the assembly + upload of A_Neu on this one: two staging sets, two host memcpy
   // streams into pinned memory.
+  // memory-bounded set-up: the eigensolve of this rank's subdomains in consecutive groups (eigen_grouped), each with its
+  // own A_Neu hierarchy -- this PC then builds none
+  eig_groups = plan_eig_groups();
+  const bool grouped = eig_groups.size() > 2;
+  info.eig_groups = (int)eig_groups.size() - 1;
+  // overlapped with the grouped eigensolves (PC::setup): both host copies and the partition of unity first, then the
+  // subdomains are released to the thread that runs eigen_grouped; nothing below reads `subs` any more
+  bool host_copies_done = false;
+  if (subs_released && grouped && !single_block) {
+    std::exception_ptr herr;
+    std::thread hc([&]() {
+      try { make_blockdiag(lvl1, suboff, nullptr, h_dirL_own); } catch (...) { herr = std::current_exception(); }
+    });
+    try { make_blockdiag(neu, suboff, nullptr, h_neuL_own); } catch (...) { if (!herr) herr = std::current_exception(); }
+    hc.join();
+    if (herr) return fail("GenEO preconditioner: host copies of the subdomain matrices failed (out of memory?)");
+    fill_partition_of_unity();
+    host_copies_done = true;
+    std::promise<bool>* pr = subs_released;
+    subs_released = nullptr;
+    pr->set_value(true);
+  }
   std::thread dir_thread([&]() {
     try {
-      if (!single_block) make_blockdiag(lvl1, suboff, nullptr, h_dirL_own);
-      bk::side_stream_begin();
+      if (!single_block && !host_copies_done) make_blockdiag(lvl1, suboff, nullptr, h_dirL_own);
+      bk::side_stream_begin(bk::get_stream(), true);
       dirL = upload_host(single_block ? *lvl1[0] : h_dirL_own);
       dirL.fine = true;
       bk::csr_make_lp(dirL);
@@ -698,13 +792,8 @@ int PC::setup_prepare() {
     }
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } dir_joiner{dir_thread};
-  if (!single_block) make_blockdiag(neu, suboff, nullptr, h_neuL_own);
+  if (!single_block && !host_copies_done) make_blockdiag(neu, suboff, nullptr, h_neuL_own);
   const HostCsr& h_neuL = single_block ? *neu[0] : h_neuL_own;
-  // memory-bounded set-up: the eigensolve of this rank's subdomains in consecutive groups (eigen_grouped), each with its
-  // own A_Neu hierarchy -- this PC then builds none
-  eig_groups = plan_eig_groups();
-  const bool grouped = eig_groups.size() > 2;
-  info.eig_groups = (int)eig_groups.size() - 1;
   const bool want1 = (opt.dls1_pc == "amg") && !eig_only;
   const bool wantN = (opt.lvl2 && opt.els2_pc == "amg") && !grouped;
   const AmgParams ap = amg_params(opt);
@@ -766,17 +855,8 @@ int PC::setup_prepare() {
   lap("A_Dir uploaded by its thread (joined)");
   // partition of unity (geneo.cpp:965-1000) and Jacobi diagonals
   {
-    std::vector<double>& D = h_Dscratch;        // kept from one set-up to the next (no page faults, no zero fill)
-    if ((int)D.size() != std::max(1, nL)) D.resize(std::max(1, nL));
-    parallel_ranges((int64_t)nL, [&](int64_t i0, int64_t i1) {       // one pass over the local space, whatever the subdomains
-      int s = (int)(std::upper_bound(suboff.begin(), suboff.end(), (int)i0) - suboff.begin()) - 1;
-      for (int64_t i = i0; i < i1;) {
-        while (s + 1 < ns && i >= suboff[s + 1]) ++s;
-        const auto& mult = subs[s].mult;
-        const int64_t e = std::min<int64_t>(i1, suboff[s + 1]);
-        for (; i < e; ++i) D[i] = 1.0 / (double)mult[i - suboff[s]];
-      }
-    });
+    if (!host_copies_done) fill_partition_of_unity();
+    std::vector<double>& D = h_Dscratch;
     d_D = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
     bk::h2d(d_D, D.data(), sizeof(double) * nL);
     d_dinv1 = (double*)bk::alloc(sizeof(double) * std::max(1, nL));
@@ -908,7 +988,7 @@ int PC::setup_prepare() {
     // work now, and side by side they took 0.16 s instead of 0.11 s on the critical path (126^3)
     if (want1 && wantN) start1();
     bk::sync();
-    info.amgSetupTime = secs(ta, clk::now());
+    info.amgSetupTime += secs(ta, clk::now());     // (+=: the groups of an overlapped set-up add theirs from another thread)
     if (getenv("GENEO_DEBUG")) fprintf(stderr, "[amg] A_Neu hierarchy (%s products) %.3f s\n", info.amg_on_device ? "device" : "host", info.amgSetupTime);
     if (want1 && !opt.lvl2)
       if (int rc = finish_amg1()) return rc;
@@ -1252,7 +1332,8 @@ int PC::apply(const double* x, double* y) {
 }
 
 // ------------------------------------------------------------------------------------ level 2
-int PC::setup_level2(const double* b_dev) {
+// the local eigensolves of level 2 (buildCoarseSpaceWithGenEO, geneo.cpp:1243-1366): eigenvalues, kept counts, Z
+int PC::setup_level2_eigen() {
   const int ns = (int)subs.size();
   auto t0 = clk::now();
   eigvals.assign(ns, {});
@@ -1271,8 +1352,14 @@ int PC::setup_level2(const double* b_dev) {
   }
   if (rc) return rc;
   bk::sync();
+  info.lvl2SetupEigTimeLoc = secs(t0, clk::now());
+  return 0;
+}
+
+int PC::setup_level2(const double* b_dev) {
+  if (!eig_early)             // (PC::setup has run them already, next to this PC's own device preparation)
+    if (int rc = setup_level2_eigen()) return rc;
   auto t1 = clk::now();
-  info.lvl2SetupEigTimeLoc = secs(t0, t1);
   if (eig_only) return 0;      // a group of eigen_grouped: Z, the eigenvalues and the counters are what the owner takes
   if (int r1 = finish_amg1()) return r1;
   t1 = clk::now();

@@ -2,6 +2,7 @@
 // MI355X-native counterpart of /root/reference/src/geneo.cpp; see DESIGN.md for the map.
 #pragma once
 #include <cstdint>
+#include <future>
 #include <memory>
 #include <string>
 #include <map>
@@ -192,6 +193,11 @@ class PC {
   bool eig_only = false;       // a group's temporary PC (eigen_grouped): the set-up stops behind the eigensolve
   std::vector<int> eig_groups; // boundaries of the subdomain groups of this set-up ({0, ns}: one group = the plain path)
   double prepare_secs = 0.0;   // time of setup_prepare (setupTime = both halves)
+  double release_secs = 0.0;   // time setup_prepare spent releasing the previous set-up (outside setupTime)
+  std::promise<bool>* subs_released = nullptr;   // PC::setup's overlapped mode: fulfilled once setup_prepare no longer reads `subs`
+  bool eig_early = false;      // the eigensolves of this set-up have run already (overlapped mode)
+  void fill_partition_of_unity();
+  int setup_level2_eigen();
   int setup_prepare();         // first half of setup(): everything the eigensolve waits for
   int setup_finish(const double* b_dev);   // second half: level 2 and the bookkeeping
   std::vector<int> plan_eig_groups() const;

@@ -38,8 +38,11 @@ def work(argv):
     n = nums[0] if nums else 126
     split = nums[1] if len(nums) > 1 else 2
     lib = _lib.load()
-    doms = [decomp.decompose_grid_domain(n, 3, (split,) * 3, 2, s) for s in range(split ** 3)]
-    a = sp.block_diag([d.a_dir for d in doms], format="csr")
+    # a third number: ONLY that subdomain of the decomposition (work 368 2 0: one 6.5 M-row subdomain of the metric's
+    # configuration -- the traffic / algorithmic ratios of the kernel classes at the bench line's per-subdomain size)
+    only = nums[2] if len(nums) > 2 else None
+    doms = [decomp.decompose_grid_domain(n, 3, (split,) * 3, 2, s, native=True) for s in (range(split ** 3) if only is None else [only])]
+    a = sp.block_diag([d.a_dir for d in doms], format="csr") if len(doms) > 1 else doms[0].a_dir.tocsr()
     rows, m = a.shape[0], 32
     h = Spmv(a, lib)
     u, v = DeviceVector.from_host(lib, np.ones(CALIB)), DeviceVector.from_host(lib, np.ones(CALIB))
