@@ -143,6 +143,7 @@ SYMBOLS = {
     "GeneoSpmvProfileStop": (C.c_int, [c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoKernelProfileStart": (C.c_int, [C.c_int, C.c_double]),
     "GeneoDeviceMemInfo": (C.c_int, [c_dbl_p] * 6 + [C.c_int]),
+    "GeneoDriverMain": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "GeneoKernelProfileStop": (C.c_int, []),
     "GeneoKernelProfileGet": (C.c_int, [C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "GeneoSpmmApply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -257,6 +257,13 @@ int GeneoPartMeshNodal(int ne, int nn, const int* eptr, const int* eind, int npa
 /* METIS_PartGraphKway on a CSR graph (symmetric adjacency, no self loops, unit weights) */
 int GeneoPartGraphKway(int n, const int* xadj, const int* adjncy, int nparts, int* objval, int* part);
 
+/* ---- the CLI driver (csrc/driver_main.cpp): counterpart of the reference executable's main() (src/geneo4PETSc.cpp:1569)
+ * with its flags (--inpFileA / --inpLibA / --inpFileB / --inpEps / --metisDual / --metisNodal / --addOverlap / --verbose /
+ * --timing / --shortRes / --cmdLine; --np N for `mpirun -n N`, --parts / --partFile for a given partition; everything else
+ * goes to the PC) and its INFO: / TIME: output lines (driver:898-1231) on stdout.  argv WITHOUT the program name.
+ * The executable geneo4petsc_amd/geneo_driver is a main() over it.  0 = ok. */
+int GeneoDriverMain(int argc, const char* const* argv);
+
 /* ---- device helpers for hosts without a HIP runtime of their own ---------------------------- */
 const char* GeneoBackendName(void);              /* "hip-gfx950" in the product library */
 PetscErrorCode GeneoSetStream(void* hip_stream); /* all launches / copies go to this stream */

@@ -23,7 +23,7 @@ def build_omp(force=False):
 
 def build(force=False, omp=False):
     srcs = [os.path.join(CSRC, "core.cpp"), os.path.join(CSRC, "amg.cpp"), os.path.join(CSRC, "capi.cpp"),
-            os.path.join(CSRC, "comm_rccl.cpp"), os.path.join(CSRC, "partition.cpp"), os.path.join(CSRC, "decompose.cpp"),
+            os.path.join(CSRC, "comm_rccl.cpp"), os.path.join(CSRC, "partition.cpp"), os.path.join(CSRC, "decompose.cpp"), os.path.join(CSRC, "driver_main.cpp"),
             os.path.join(HERE, "backend_host.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("core.h", "backend.h", "dense.h", "amg.h")] + \
         [os.path.join(ROOT, "include", "geneo_c.h")]
