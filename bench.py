@@ -763,7 +763,9 @@ def main():
                 prof = {}
             for k in kernels:
                 key = k["kernel"].split(" ")[0]
-                hits = [v for name, v in prof.items() if isinstance(v, dict) and name.startswith(key) and "traffic_over_algorithmic" in v]
+                hits = [v for name, v in prof.items() if isinstance(v, dict) and (name == key or name.startswith(key + "<") or name.startswith(key + "_ld"))
+                        and "traffic_over_algorithmic" in v]
+                hits.sort(key=lambda v: -v["traffic_over_algorithmic"])      # several forms of a class measured: the worst ratio
                 # the ratio of a class is a property of the matrix the XCDs walk: applied when the profile was measured on
                 # this rank's rows or on ONE of its (equal) subdomains
                 prow = hits[0].get("rows", info_rows) if hits else 0

@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96", "k_gram_flat": "gram96",
+KERNELS = {"k_spmv_sell<": "spmv", "k_spmv_sell_lp<": "spmv_lp_pre", "k_spmv_sell_p8": "spmv", "k_spmm_sell": "spmm32", "k_spmm<": "spmm32_csr", "k_gram_mfma": "gram96", "k_gram_flat": "gram96",
            "k_blockmul_mfma": "blockmul96x64", "k_lobpcg_update32<1>": "lobpcg_update32_basis", "k_lobpcg_update32<3>": "lobpcg_update32"}
 CALIB = 40_000_000
 
@@ -58,6 +58,12 @@ def work(argv):
     for _ in range(6):
         evict()
         lib.GeneoSpmvApply(h.h, x.ptr, y.ptr)
+    # the zero-guess sweep + residual of the V-cycle on the single-precision companion (EPI_PRE: b in, r out): the pass the
+    # local solves launch on the fine matrix, k_spmv_sell_lp<4, 1, unsigned short, ..>
+    dinv = DeviceVector.from_host(lib, np.random.default_rng(7).random(rows) + 0.5)
+    for _ in range(6):
+        evict()
+        lib.GeneoSpmvFusedSingle(h.h, 4, None, y.ptr, x.ptr, None, dinv.ptr, C.c_double(0.7))
     for ld in (32, 96):
         for _ in range(6):
             evict()
@@ -65,6 +71,7 @@ def work(argv):
     lib.GeneoDeviceSync()
     alg = {"calib_elems": CALIB, "rows": rows, "nnz": int(a.nnz),
            "spmv": a.nnz * 12 + (rows + 1) * 4 + rows * 16,
+           "spmv_lp_pre": a.nnz * 6 + (rows // 64 + 1) * 4 + rows * 16,
            "spmm32": a.nnz * 12 + rows * 4 + 16 * m * rows,
            "gram96": 8 * rows * (96 + 96), "blockmul96x64": 8 * rows * (96 + 64),
            "lobpcg_update32": 8 * rows * (3 * 96 + 3 * 64 + 32), "lobpcg_update32_basis": 8 * rows * (96 + 64)}
