@@ -464,6 +464,7 @@ def one_rank_of(args):
         "first_setup_s": {"setup": cold[1], "solve": cold[2], "wall": cold[0],
                           "note": "first set-up of the process: allocator empty, every block from hipMalloc"},
         "iterations": its, "converged": reason, "dimE": info["dimE"], "eig_iterations": info["eig_iterations"],
+        "eig_coarse_iterations": info.get("eigCoarseIterations"),
         "local_solve_cg_iterations": info["dls1_iterations"], "local_solves": info["dls1_solves"],
         "amg_levels": info["amg_levels"], "amg_setup_s": info["amgSetupTime"], "host_prep_s": prep_s,
         "setup_breakdown_s": {"level1_upload_and_amg": info["lvl1SetupMinvTimeLoc"],
@@ -814,6 +815,7 @@ def main():
             "scaling": args.scaling if args.workload == "laplacian" else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "device_mem_peak_gb": mem["device_mem_peak_gb"], "device_memory": mem, "eig_groups": info.get("eigGroups"),
+            "eig_coarse_iterations": info.get("eigCoarseIterations"),   # > 0: the eigensolves started from the multigrid level-1 pencil
             "transport_fallback": transport_fallback,      # not None: this is NOT a measurement of the C++ RCCL transport
             "config": {"workload": (wl_desc + ", -geneo_lvl %s, -geneo_cut %d, tau %.2f, -els2_eps_tol %g, PCG rtol %.0e"
                                     % (args.lvl, args.cut, args.tau, args.eps_tol, args.rtol)) if wl_desc else

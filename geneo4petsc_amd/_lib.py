@@ -35,7 +35,8 @@ class GeneoInfo(C.Structure):
                                           "lvl1ApplyPrjFSTimeLoc", "lvl2ApplyTimeLoc", "lvl2ApplyZtTimeLoc",
                                           "lvl2ApplyEinvTimeLoc", "lvl2ApplyZTimeLoc", "setupTime", "solveTime")] + \
                [("amg_levels", C.c_int), ("amg_operator_complexity", C.c_double), ("amgSetupTime", C.c_double),
-                ("nullPivotsLoc", C.c_int), ("eigGroups", C.c_int)]
+                ("nullPivotsLoc", C.c_int), ("eigGroups", C.c_int),
+                ("eigCoarseIterations", C.c_int)]
 
 
 class GeneoDomain(C.Structure):

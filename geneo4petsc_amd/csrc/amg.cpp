@@ -606,6 +606,7 @@ void AmgDevice::upload(const std::vector<AmgLevelHost>& levels, const std::vecto
     }
     if (l == 0) nnz0 = (double)H.nnz;
     nnzt += (double)H.nnz;
+    L.suboff = H.suboff;
     lv.push_back(L);
   }
   opc = nnz0 > 0 ? nnzt / nnz0 : 1.0;
@@ -801,6 +802,7 @@ bool AmgDevice::build_on_device(const HostCsr& A, const std::vector<int>& suboff
     L.n = Ah.n;
     L.A = Adev;
     L.own_A = own;
+    L.suboff = so;
     // host part of the level (diagonal, Gershgorin bound, aggregates): level 0 may have been computed early by the caller
     AmgLevelHostPart hp_own;
     if (l == 0 && level0) {
@@ -981,6 +983,12 @@ void AmgDevice::cycle(int l, const double* B, int ldb, double* X, int ldx, int m
   applyA(L.P, C.x, m, L.d, m, m);                                          // prolong + correct
   bk::block_axpby(X, ldx, 1.0, L.d, m, 1.0, L.n, m);
   smooth(L, B, ldb, X, ldx, m, false);                                     // post-smoothing
+}
+
+void AmgDevice::vcycle_from(int l, const double* B, int ldb, double* X, int ldx, int m) {
+  if (m > maxm) throw std::runtime_error("AMG: block wider than the hierarchy was allocated for");
+  if (l < 0 || l >= (int)lv.size()) throw std::runtime_error("AMG: no such level");
+  cycle(l, B, ldb, X, ldx, m);
 }
 
 void AmgDevice::vcycle(const double* B, int ldb, double* X, int ldx, int m) {

@@ -73,6 +73,16 @@ class AmgDevice {
   double operator_complexity() const { return opc; }
   void free_all();
   int lp_matrices() const { return nlp; }   // level matrices that carry a single-precision companion
+  // The hierarchy from level l down as a preconditioner of ITS level matrix (the eigensolver's coarse start: LOBPCG on the
+  // Galerkin pencil of level 1 before the fine one); B, X: n_l x m.  Level views for that caller: matrix, transfer
+  // operators, Jacobi diagonal and the subdomain offsets of a level (borrowed; valid while the hierarchy lives).
+  void vcycle_from(int l, const double* B, int ldb, double* X, int ldx, int m);
+  const bk::Csr& level_A(int l) const { return lv[l].A; }
+  const bk::Csr& level_P(int l) const { return lv[l].P; }     // n_l x n_{l+1}
+  const bk::Csr& level_R(int l) const { return lv[l].R; }
+  const double* level_dinv(int l) const { return lv[l].dinv; }
+  int level_rows(int l) const { return lv[l].n; }
+  const std::vector<int>& level_suboff(int l) const { return lv[l].suboff; }
 
  private:
   struct Lvl {
@@ -87,6 +97,7 @@ class AmgDevice {
     bool own_A = true;
     bool own_lp_A = false;    // the single-precision companion of a BORROWED level-0 matrix was made here (else its owner made it)
     bool fused = false;       // A and P have no long-row remainder: fused-epilogue cycle
+    std::vector<int> suboff;  // row offsets of the subdomain blocks on this level (host)
   };
   std::vector<Lvl> lv;
   bk::Chunks cch;              // chunks of the coarsest level (per subdomain)

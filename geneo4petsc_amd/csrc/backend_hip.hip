@@ -628,6 +628,46 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
 // the same blob ask for it; only the blob's surface is fetched twice.  Adjacency is sampled (4 rows per slice): the
 // schedule is a traversal order, not part of the result.  Returns an empty vector when the natural order already keeps
 // the neighbours within reach.
+// Strip schedule for matrices with ONE far offset F per block (a 3-D stencil in natural order: F = a grid plane).  The
+// blobs above bound the over-fetch of the +-F neighbours by their surface (1.56 x algorithmic at 6.5 M rows per block);
+// a sweep does better: the plane is cut into strips of W consecutive rows (position of a row in its plane = row mod F),
+// and a strip is walked through ALL planes before the next strip starts.  The +-F neighbours of the rows in flight are
+// then the same strip one plane behind (already in the group's L2: it was the centre a moment ago) and one plane ahead
+// (fetched now, the centre next): every row of X comes in once, plus the two lines either side of a strip (+-nx
+// neighbours across the strip edge).  Needs nothing but F: slices are grouped into runs of equal furthest offset
+// (blocks of a flat block-diagonal matrix may differ), the origin of a run stands for the block's first row (a shift
+// of the origin only rotates the strips).  Empty when less than 80 % of the slices lie in runs of three planes or more
+// (irregular matrices: the blobs stay).
+static std::vector<int> strip_schedule(int nslice, const std::vector<int>& frow) {
+  static const int WT = getenv("GENEO_SPMM_STRIP") ? atoi(getenv("GENEO_SPMM_STRIP")) : 3072;   // rows of a strip (target)
+  std::vector<int> order;
+  order.reserve(nslice);
+  int64_t covered = 0;
+  std::vector<std::vector<int>> bucket;
+  for (int sa = 0; sa < nslice;) {
+    int sb = sa + 1;
+    while (sb < nslice && frow[sb] == frow[sa]) ++sb;
+    const int F = frow[sa];
+    const bool swept = F >= 4 * WT && (int64_t)(sb - sa) * 64 >= (int64_t)3 * F;
+    if (!swept) {
+      for (int s = sa; s < sb; ++s) order.push_back(s);
+    } else {
+      const int nst = std::max(1, (F + WT / 2) / WT);
+      const int W = (F + nst - 1) / nst;
+      bucket.assign(nst, {});
+      for (int s = sa; s < sb; ++s) bucket[(int)((((int64_t)(s - sa) * 64) % F) / W)].push_back(s);
+      for (int b = 0; b < nst; ++b) order.insert(order.end(), bucket[b].begin(), bucket[b].end());
+      covered += sb - sa;
+    }
+    sa = sb;
+  }
+  if (covered * 10 < (int64_t)nslice * 8) return {};
+  if (getenv("GENEO_DEBUG_SCHED"))
+    fprintf(stderr, "[sched] strip: %d slices, %lld swept, far offset of the first run %d rows, strip target %d rows\n", nslice,
+            (long long)covered, frow[0], WT);
+  return order;
+}
+
 static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_col, int nslice) {
   static const int TILE = getenv("GENEO_SPMM_TILE") ? atoi(getenv("GENEO_SPMM_TILE")) : 512;
   static const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto)
@@ -642,6 +682,7 @@ static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_c
   std::vector<std::vector<int>> part_adj(nth);
   std::vector<int> part_far(nth, 0);
   std::vector<int> cnts((size_t)nslice, 0);
+  std::vector<int> frow((size_t)nslice, 0);   // furthest column of the probed rows, in rows (a grid plane for a 3-D stencil)
   auto sample = [&](int t) {
     const int s0 = (int)((int64_t)nslice * t / nth), s1 = (int)((int64_t)nslice * (t + 1) / nth);
     std::vector<int>& out = part_adj[t];
@@ -655,6 +696,7 @@ static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_c
       for (int t4 = 0; t4 < 4; ++t4) {
         const int r = std::min(probe[t4], r1 - 1);
         for (int k = h_rowptr[r]; k < h_rowptr[r + 1] && cnt < CAP; ++k) {
+          frow[s] = std::max(frow[s], std::abs(h_col[k] - r));
           const int o = h_col[k] >> 6;
           if (o == s || o >= nslice) continue;
           bool seen = false;
@@ -683,6 +725,10 @@ static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_c
   for (int s = 0; s < nslice; ++s) adj_ptr[s + 1] = adj_ptr[s] + cnts[s];
   // natural order keeps the far neighbours in flight while they are within a fraction of the slices a group holds
   if (!(mode && !strcmp(mode, "blob")) && far < TILE / 4) return {};
+  if (!(mode && !strcmp(mode, "blob"))) {
+    std::vector<int> order = strip_schedule(nslice, frow);
+    if (!order.empty()) return order;
+  }
   adj.reserve((size_t)adj_ptr[nslice]);
   for (int t = 0; t < nth; ++t) adj.insert(adj.end(), part_adj[t].begin(), part_adj[t].end());
   std::vector<int> order;

@@ -145,6 +145,7 @@ std::string parse_option(Options& o, const std::string& key, const std::string& 
   }
   if (key == "-geneo_eig_group_rows") return integer(o.eig_group_rows);
   if (key == "-geneo_eig_mem_gb") return dbl(o.eig_mem_gb);
+  if (key == "-geneo_eig_coarse_start") return integer(o.eig_coarse_start);
   if (key == "-els2_eps_seed") { int v; if (!to_int(value, v)) return "bad seed"; o.eps_seed = (uint64_t)v; return ""; }
   if (key == "-dls1_ksp_rtol") return dbl(o.dls1_rtol);
   if (key == "-dls1_ksp_max_it") return integer(o.dls1_max_it);
@@ -1631,6 +1632,10 @@ thread_local bool HostPool::in_pool_work = false;
 // (n_L x m, row-major, device) the B-orthonormal Ritz vectors.
 int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc) {
   const int ns = (int)subs.size();
+  // the rows the pencil lives on: the rank's fine rows, or those of a multigrid level (coarse start)
+  const int nL = P.rows >= 0 ? P.rows : this->nL;
+  const bk::Chunks& ch = P.chunks ? *P.chunks : this->ch;
+  auto rows_of = [&](int s) { return P.row_off ? P.row_off[s + 1] - P.row_off[s] : (int)subs[s].l2g.size(); };
   const int nev_try = P.nev_try;
   const int p3 = 3 * m;
   const size_t blk = (size_t)nL * p3;
@@ -1710,7 +1715,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
   };
   // ---- start block + Rayleigh-Ritz on X alone
-  bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed + (uint64_t)P.seed_off);
+  if (P.X0) bk::block_axpby(S, p3, 1.0, P.X0, m, 0.0, nL, m);
+  else bk::block_init(ch, S, p3, m, d_subgid, opt.eps_seed + (uint64_t)P.seed_off);
   deflate(S, p3);
   applyA(S, AS);
   applyB(S, BS);
@@ -1735,7 +1741,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   void* gram_ev[2] = {nullptr, nullptr};
   if (pipeline_ok) {
     std::vector<int> so(ns + 1, 0);
-    for (int s = 0; s < ns; ++s) so[s + 1] = so[s] + (int)subs[s].l2g.size();
+    for (int s = 0; s < ns; ++s) so[s + 1] = so[s] + rows_of(s);
     int cut = 1;                                                 // the split that balances the rows of the two groups
     for (int s = 1; s < ns; ++s)
       if (std::abs(2 * (int64_t)so[s] - so[ns]) < std::abs(2 * (int64_t)so[cut] - so[ns])) cut = s;
@@ -1925,7 +1931,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
   bool all_done = false;
   std::vector<int> nev_s(ns);
   for (int s = 0; s < ns; ++s)
-    nev_s[s] = std::max(0, std::min(nev_try, (int)subs[s].l2g.size() - (P.locked_cols ? P.locked_cols[s] : 0)));
+    nev_s[s] = std::max(0, std::min(nev_try, rows_of(s) - (P.locked_cols ? P.locked_cols[s] : 0)));
   static const bool nolock = getenv("GENEO_LOBPCG_NOLOCK") != nullptr;
   std::vector<double> lam_prev((size_t)ns * m, 1e300);   // Ritz values of the previous iteration (straggler test)
   // A pair is ACCEPTED at the tolerance but keeps iterating (its W / P columns stay in the basis) until it is far below
@@ -2003,7 +2009,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     fprintf(stderr, " | lam0 %.6e %.6e .. %.6e | pc %s\n", lam[0], lam[1], lam[std::max(1, nev_s[0]) - 1], P.amg ? "amg" : "cheb");
   };
-  for (it = 0; it <= opt.eps_max_it; ++it) {
+  const int max_it = P.max_it > 0 ? P.max_it : opt.eps_max_it;
+  for (it = 0; it <= max_it; ++it) {
     // the A X / B X blocks are carried by recurrence (A S C); refresh them explicitly every few
     // iterations so that rounding drift (eps * ||A|| ||x|| per update, large for high-contrast
     // operators) cannot accumulate into the residual
@@ -2027,7 +2034,8 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     auto precondition = [&]() {
       if (P.amg) {
         // W = T r : one smoothed-aggregation V-cycle of A on the whole block (~ shift-invert at sigma = 0)
-        P.amg->vcycle(cr, m, W, p3, m);
+        if (P.amg_level > 0) P.amg->vcycle_from(P.amg_level, cr, m, W, p3, m);
+        else P.amg->vcycle(cr, m, W, p3, m);
         info.eig_spmm += 3;
       } else {
         // W = T r : Chebyshev iteration on A z = r with Jacobi scaling, z0 = 0 (Saad, Alg. 12.1)
@@ -2088,7 +2096,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         }
       all_done = update_locks();
       debug_line();
-      if (all_done || it == opt.eps_max_it) break;
+      if (all_done || it == max_it) break;
       precondition();
       applyA(W, AS + 2 * m);
       applyB(W, BS + 2 * m);
@@ -2177,7 +2185,7 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
         // an unconverged subdomain rules `all` out, so no Ritz value of a finished run is ever overwritten)
         all_done = all;
         debug_line();
-        if (all_done || it == opt.eps_max_it) { stop = true; break; }
+        if (all_done || it == max_it) { stop = true; break; }
       }
       // soft locking without extra passes: the P columns of locked pairs are dropped through the Rayleigh-Ritz
       // coefficients (rr_one) and their residual columns through the mask of the next block_residual_norms
@@ -2193,14 +2201,15 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
     }
     if (stop) break;
   }
-  info.eig_iterations += it;
-  if (all_done) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
+  if (P.iterations) *P.iterations += it;
+  else info.eig_iterations += it;
+  if (all_done || P.max_it > 0) bk::block_axpby(Xc, m, 1.0, S, p3, 0.0, nL, m);
   bk::sync();
   if (getenv("GENEO_DEBUG"))
     fprintf(stderr, "[lobpcg %s] %d iterations (%s) %.3f s: host Rayleigh-Ritz %.3f s (+ %.3f s of Gram propagation behind the device phase), waiting for the Gram blocks %.3f s\n", P.label, it,
             lean ? "lean: S alone carried" : "A S, B S carried", secs(t_lob0, clk::now()), t_rr_host, t_prop_host, t_dev_wait);
   cleanup();
-  if (!all_done) {
+  if (!all_done && P.max_it <= 0) {
     // The reference aborts on EPS_DIVERGED_ITS (checkEPSSolve, geneo.cpp:577-624).
     std::ostringstream msg;
     msg << "GenEO preconditioner: els2-" << P.label << " KO (EPS_DIVERGED_ITS after " << it << " LOBPCG iterations)";
@@ -2375,6 +2384,7 @@ int PC::eigen_lobpcg() {
       cur.X = dv((size_t)nL * mm);
       cur.m = mm;
       if (int rc = lobpcg_solve(P, mm, cur.lam, cur.X)) { bk::dfree(cur.X); return rc; }
+      P.X0 = nullptr;                 // a start block belongs to the first solve (its width)
       cur.count.assign(ns, 0);
       for (int s = 0; s < ns; ++s) cur.count[s] = std::min(nev, (int)subs[s].l2g.size());
       if (opt.cut > 0 || opt.noSyl || opt.eps_block > 0) { out.push_back(cur); return 0; }
@@ -2459,6 +2469,99 @@ int PC::eigen_lobpcg() {
       cur = nxt;
     }
   };
+  // Coarse start (Options::eig_coarse_start): Ritz vectors of the Galerkin pencil of multigrid level 1, prolonged -- that
+  // solve itself started from level 2, and so on down while a level still holds enough rows for the block (nested
+  // iteration).  nullptr: does not apply here (GenEO-2, no hierarchy, small subdomains, the block-growing path without
+  // -geneo_cut) or a coarse solve did not deliver m independent pairs per subdomain -- the fine solve then starts from
+  // its seeded random block as before.
+  info.eig_coarse_iterations = 0;
+  // Ritz vectors (rows of level l x m) of the pencil (A_l, Bl) for l >= 1; nullptr on failure.  Bl is borrowed.
+  std::function<double*(int, const bk::Csr&)> level_vectors = [&](int l, const bk::Csr& Bl) -> double* {
+    // (read per set-up: tests lower the row bound to reach the nested form on small grids)
+    const int min_rows = getenv("GENEO_COARSE_START_MIN_ROWS") ? atoi(getenv("GENEO_COARSE_START_MIN_ROWS")) : 20000;
+    const double ctol = getenv("GENEO_COARSE_START_TOL") ? atof(getenv("GENEO_COARSE_START_TOL")) : 1e-2;
+    const std::vector<int>& so = amgN->level_suboff(l);
+    const int nl = amgN->level_rows(l);
+    const auto t0 = clk::now();
+    double* X0 = nullptr;
+    if (l + 1 < amgN->nlevels()) {        // one level further down first, if it still carries the block comfortably
+      const std::vector<int>& co = amgN->level_suboff(l + 1);
+      bool deeper = (int)co.size() == ns + 1 && (int64_t)amgN->level_rows(l + 1) >= (int64_t)min_rows * ns;
+      for (int s = 0; deeper && s < ns; ++s) deeper = co[s + 1] - co[s] >= 4 * m;
+      if (deeper) {
+        const int nc = amgN->level_rows(l + 1);
+        bool ok = true;
+        bk::Csr BP = bk::spgemm(Bl, amgN->level_P(l), nc, &ok);
+        if (ok) {
+          bk::Csr Bc = bk::spgemm(amgN->level_R(l), BP, nc, &ok);
+          bk::csr_free(BP);
+          if (ok) {
+            bk::csr_finish(Bc);
+            double* Xc = level_vectors(l + 1, Bc);
+            if (Xc) {
+              X0 = dv((size_t)nl * m);
+              bk::spmm_strided(amgN->level_P(l), Xc, m, X0, m, m, nullptr, nullptr);
+              bk::dfree(Xc);
+            }
+            bk::csr_free(Bc);
+          }
+        }
+      }
+    }
+    const auto t1 = clk::now();
+    bk::Chunks cc = bk::chunks_upload(ns, so.data());
+    EigProblem pc{&amgN->level_A(l), nullptr, &Bl, nullptr, amgN, amgN->level_dinv(l), cheb_lmax, nev_try, "tau-coarse"};
+    pc.rows = nl;
+    pc.chunks = &cc;
+    pc.row_off = so.data();
+    pc.amg_level = l;
+    pc.tol = std::max(opt.eps_tol, ctol);     // a start block: the discretisation gap between two levels is larger than this
+    pc.iterations = &info.eig_coarse_iterations;
+    pc.max_it = 40;
+    pc.X0 = X0;
+    std::vector<double> lamc;
+    double* Xl = dv((size_t)nl * m);
+    const int before = info.eig_coarse_iterations;
+    const int rc = lobpcg_solve(pc, m, lamc, Xl);
+    bool full = rc == 0;
+    for (size_t e = 0; full && e < lamc.size(); ++e) full = lamc[e] < 1e299;
+    if (rc) last_error.clear();               // the coarse attempt is optional: its failure is not the set-up's
+    if (X0) bk::dfree(X0);
+    bk::chunks_free(cc);
+    if (!full) { bk::dfree(Xl); Xl = nullptr; }
+    if (getenv("GENEO_DEBUG")) {
+      bk::sync();
+      fprintf(stderr, "[coarse start] level %d: %d rows, levels below + B products %.3f s, %d LOBPCG iterations %.3f s%s\n", l, nl,
+              secs(t0, t1), info.eig_coarse_iterations - before, secs(t1, clk::now()), full ? "" : " -- not used");
+    }
+    return Xl;
+  };
+  auto coarse_start = [&]() -> double* {
+    if (g2 || !amgN || opt.els2_pc != "amg" || opt.eig_coarse_start <= 0 || ns == 0) return nullptr;
+    if (!(opt.cut > 0 || opt.noSyl || opt.eps_block > 0)) return nullptr;
+    if ((int64_t)nL < (int64_t)opt.eig_coarse_start * ns || amgN->nlevels() < 2) return nullptr;
+    const std::vector<int>& co = amgN->level_suboff(1);
+    if ((int)co.size() != ns + 1) return nullptr;
+    for (int s = 0; s < ns; ++s)
+      if (co[s + 1] - co[s] < 4 * m) return nullptr;
+    const int nc = amgN->level_rows(1);
+    bool ok = true;
+    bk::Csr BP = bk::spgemm(dirBD, amgN->level_P(0), nc, &ok);
+    if (!ok) return nullptr;
+    bk::Csr Bc = bk::spgemm(amgN->level_R(0), BP, nc, &ok);
+    bk::csr_free(BP);
+    if (!ok) return nullptr;
+    bk::csr_finish(Bc);
+    double* X0 = nullptr;
+    double* Xc = level_vectors(1, Bc);
+    if (Xc) {
+      X0 = dv((size_t)nL * m);
+      bk::spmm_strided(amgN->level_P(0), Xc, m, X0, m, m, nullptr, nullptr);
+      bk::dfree(Xc);
+    }
+    bk::csr_free(Bc);
+    return X0;
+  };
   std::vector<Stage> stT, stG;
   auto release_all = [&]() {
     free_stages(stT);
@@ -2477,7 +2580,11 @@ int PC::eigen_lobpcg() {
     }
     if (opt.check)
       if (int rc = check_local_spd(pt, hostB.data(), !g2)) { release_all(); return rc; }
-    if (int rc = solve_grow(pt, false, stT)) { release_all(); return rc; }
+    double* X0 = coarse_start();
+    pt.X0 = X0;
+    const int rc_tau = solve_grow(pt, false, stT);
+    if (X0) bk::dfree(X0);
+    if (rc_tau) { release_all(); return rc_tau; }
   }
   if (g2) {
     if (int rc = local_gamma()) { release_all(); return rc; }
@@ -2681,6 +2788,7 @@ int PC::eigen_grouped() {
   const int ng = (int)eig_groups.size() - 1;
   ksub.assign(ns, 0);
   info.eig_iterations = 0;
+  info.eig_coarse_iterations = 0;
   std::vector<double*> zpiece(ng, nullptr);
   auto drop_pieces = [&]() {
     for (double* p : zpiece) bk::dfree(p);
@@ -2762,6 +2870,7 @@ int PC::eigen_grouped() {
     info.nicolaidesLoc += q.info.nicolaidesLoc;
     info.estimDimELoc += q.info.estimDimELoc;
     info.eig_iterations = std::max(info.eig_iterations, q.info.eig_iterations);   // as in one batch: the slowest subdomain's
+    info.eig_coarse_iterations = std::max(info.eig_coarse_iterations, q.info.eig_coarse_iterations);
     info.eig_spmm += q.info.eig_spmm;
     info.amgSetupTime += q.info.amgSetupTime;
     if (g == 0) {

@@ -53,6 +53,12 @@ struct Options {
   //   eig_mem_gb     > 0: device-memory budget of one group's eigensolve in GiB;  0: 35 % of the card (unknown card: one group)
   int eig_group_rows = 0;
   double eig_mem_gb = 0.0;
+  // Coarse start of the local eigensolves (-geneo_eig_coarse_start R): when the rank's subdomains hold at least R rows each
+  // on average, LOBPCG first runs on the Galerkin pencil of multigrid level 1 (A_c = P^T A_Neu P from the hierarchy,
+  // B_c = P^T D A_Dir D P: two sparse products) and the fine iteration starts from the prolonged Ritz vectors instead of a
+  // random block: an iteration there costs an eighth of a fine one and the fine solve is left with the last digits.  The
+  // fine pairs meet the same convergence test either way.  0: never.
+  int eig_coarse_start = 750000;
   // -dls1_ : local "direct" solve replaced by batched Jacobi-PCG driven to a tight tolerance
   double dls1_rtol = 1e-12;
   int dls1_max_it = 20000;
@@ -98,6 +104,7 @@ struct Info {                 // public counters / timers of geneoContext (hdr/g
   long long spmv_calls = 0;
   int amg_levels = 0, amg_on_device = 0;
   int eig_groups = 1;          // consecutive subdomain groups the eigensolve ran in (memory-bounded set-up)
+  int eig_coarse_iterations = 0;   // LOBPCG iterations on the multigrid level-1 pencil (coarse start; 0: not used)
   double amg_operator_complexity = 0.0, amgSetupTime = 0.0;
   int nullPivotsLoc = 0;
 };
@@ -234,6 +241,16 @@ class PC {
     // A and B on ONE sliced pattern (bk::spmm_dual): A W and B W of an iteration in one pass over W
     const bk::Csr* dual_pat = nullptr;
     const double *dual_vA = nullptr, *dual_vB = nullptr;
+    // A pencil that does not live on the fine rows (the coarse start of eigen_lobpcg: the Galerkin pencil of multigrid
+    // level `amg_level`): its row count, the chunks of its subdomain blocks and the blocks' row offsets (ns + 1)
+    int rows = -1;
+    const bk::Chunks* chunks = nullptr;
+    const int* row_off = nullptr;
+    int amg_level = 0;                    // the V-cycle starts at this level of `amg`
+    const double* X0 = nullptr;           // start block (rows x m row-major, device) instead of the seeded random one
+    int* iterations = nullptr;            // where the iteration count goes (default: info.eig_iterations)
+    int max_it = 0;                       // > 0: at most this many iterations, and the block is handed back as it stands then
+                                          // (a start block for the next level does not have to meet the tolerance)
   };
   int lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, double* Xc);
   int eig_targets(int* nev_try) const;

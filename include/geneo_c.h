@@ -191,6 +191,8 @@ typedef struct {
                                            subdomain matrices; the reference's MUMPS settings of tuneSolver, geneo.cpp:76-92) */
   int eigGroups;                        /* consecutive subdomain groups the local eigensolves of this set-up ran in (1: all at once;
                                            > 1: memory-bounded set-up, -geneo_eig_group_rows / -geneo_eig_mem_gb) */
+  int eigCoarseIterations;              /* LOBPCG iterations spent on the multigrid level-1 pencil whose Ritz vectors start the fine
+                                           eigensolve (-geneo_eig_coarse_start; 0: the fine eigensolve started from its random block) */
 } GeneoInfo;
 PetscErrorCode PCGenEOGetInfo(GENEO_PC pc, GeneoInfo* info);
 /* eigenvalues kept in Z for local subdomain s (returns the count; copies min(count, cap)) */

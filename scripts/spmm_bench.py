@@ -27,6 +27,8 @@ def main():
     reps = int(os.environ.get("REPS", "20"))
     lib = _lib.load()
     nb = split ** 3
+    if os.environ.get("ONE"):          # ONE=1: the first subdomain of the decomposition alone
+        nb = 1
     doms = [decomp.decompose_grid_domain(n, 3, (split,) * 3, 2, s) for s in range(nb)]
     a = sp.block_diag([d.a_dir for d in doms], format="csr")
     rows = a.shape[0]

@@ -240,3 +240,28 @@ def check_grouped_eigensolve(lib, n=14, overlap=2, extra=(), group_rows=(1, 3000
             assert worst["E"] <= 1e-8 and worst["x"] <= 1e-6, worst
     assert runs[1]["info"]["eigGroups"] == 8
     return runs, worst
+
+
+def check_coarse_start(lib, n, extra=(), ev_rtol=1e-8, expect_levels=()):
+    """-geneo_eig_coarse_start (the local eigensolve started from the Ritz vectors of the multigrid level-1 pencil, that one
+    from level 2, ...): a start block, nothing else -- at a tight eigenvalue tolerance the kept eigenvalues, the kept counts,
+    dimE and the outer iteration count are those of the seeded random start.  Returns (info without, info with, worst
+    relative eigenvalue difference)."""
+    mesh, dec, a, b = grid_case(n=n, dim=3, parts=(2, 2, 2), overlap=2)
+    runs = []
+    for cs in (0, 1):
+        pc = run_pc(lib, mesh, dec, bench_argv(["-els2_eps_tol", "1e-10", "-geneo_eig_coarse_start", str(cs)] + list(extra)), b)
+        x, its, rnorm, reason = pc.solve(b)
+        runs.append(dict(ev=[pc.eigenvalues(s) for s in range(8)], dims=list(pc.local_dims()), its=its, x=x, reason=reason,
+                         info=pc.info()))
+        pc.destroy()
+    off, on = runs
+    assert off["info"]["eigCoarseIterations"] == 0 and on["info"]["eigCoarseIterations"] > 0
+    assert on["reason"].startswith("KSP_CONVERGED") and on["its"] == off["its"], (on["its"], off["its"])
+    assert on["dims"] == off["dims"] and on["info"]["dimE"] == off["info"]["dimE"]
+    worst = 0.0
+    for s in range(8):
+        np.testing.assert_allclose(on["ev"][s], off["ev"][s], rtol=ev_rtol, atol=1e-13)
+        worst = max(worst, float(np.max(np.abs(on["ev"][s] - off["ev"][s]) / np.abs(off["ev"][s]))))
+    assert np.linalg.norm(on["x"] - off["x"]) <= 1e-6 * np.linalg.norm(off["x"])
+    return off["info"], on["info"], worst

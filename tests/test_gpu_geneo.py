@@ -326,6 +326,22 @@ def test_cooperative_reductions_of_large_subdomains(lib, lvl, ksp, overlap):
     assert its == its_default and info["dimE"] == info_default["dimE"]
 
 
+def test_eigensolve_coarse_start_nested(lib, monkeypatch, capfd):
+    """VERDICT r3 item 8 (cut LOBPCG's iterations): -geneo_eig_coarse_start -- the fine eigensolve starts from the prolonged
+    Ritz vectors of the level-1 Galerkin pencil, that solve from level 2 (nested iteration; the row bound of the nesting is
+    lowered so that a 64^3 grid reaches it).  At a tight tolerance: the eigenvalues of the random start to 1e-8, the same
+    kept counts, dimE and PCG count.  (What it buys is measured at 6.5 M rows per subdomain: 19 -> 7 fine iterations,
+    profiles/r04_coarse_start_ab.log; below ~0.5 M rows it does not pay and the default threshold keeps it out.)"""
+    monkeypatch.setenv("GENEO_COARSE_START_MIN_ROWS", "1")
+    monkeypatch.setenv("GENEO_DEBUG", "1")
+    off, on, worst = cases.check_coarse_start(lib, n=64)
+    err = capfd.readouterr().err
+    assert "[coarse start] level 2" in err and "[coarse start] level 1" in err and "not used" not in err
+    assert on["dimE"] == 160
+    print("coarse start at 64^3: %d coarse + %d fine LOBPCG iterations (random start: %d), worst relative eigenvalue difference %.1e"
+          % (on["eigCoarseIterations"], on["eig_iterations"], off["eig_iterations"], worst))
+
+
 def test_memory_bounded_setup_groups_give_the_ungrouped_result(lib):
     """the rank's subdomains eigensolved in consecutive groups under a device-memory budget
     (-geneo_eig_group_rows; what lets 368^3 in 8 subdomains fit ONE GPU) at the bench's own options: kept counts, dimE,

@@ -316,6 +316,27 @@ def test_memory_bounded_setup_without_cut_and_with_the_chebyshev_eigensolver(lib
     assert np.array_equal(res[0][1], res[1][1])
 
 
+def test_eigensolve_coarse_start_gives_the_same_eigenpairs(lib):
+    """-geneo_eig_coarse_start 1: LOBPCG on the Galerkin pencil of multigrid level 1 (A_c from the A_Neu hierarchy,
+    B_c = P^T D A_Dir D P), its Ritz vectors prolonged as the start block of the fine iteration.  At a tight tolerance
+    the result is the one of the random start: kept eigenvalues to 1e-8, kept counts, dimE, the PCG count."""
+    off, on, worst = cases.check_coarse_start(lib, n=20, extra=["-geneo_cut", "8"])
+    assert on["amg_levels"] >= 2
+    print("coarse start: %d coarse + %d fine LOBPCG iterations (random start: %d), worst relative eigenvalue difference %.1e"
+          % (on["eigCoarseIterations"], on["eig_iterations"], off["eig_iterations"], worst))
+
+
+def test_eigensolve_coarse_start_stays_out_where_it_does_not_apply(lib):
+    """small subdomains (default threshold), GenEO-2, and the block-growing path without -geneo_cut keep the random start"""
+    mesh, dec, a, b = cases.grid_case(n=14, dim=3, parts=(2, 2, 2), overlap=2)
+    for argv in (cases.bench_argv(),                                                        # 1 000 rows per subdomain < 750 000
+                 cases.bench_argv(["-geneo_eig_coarse_start", "1", "-geneo_lvl", "SORAS,2", "-geneo_optim", "0.5"]),
+                 ["-geneo_lvl", "ASM,1", "-geneo_tau", "0.2", "-ksp_type", "gmres", "-geneo_eig_coarse_start", "1"] + TIGHT):
+        pc = cases.run_pc(lib, mesh, dec, argv, b)
+        assert pc.info()["eigCoarseIterations"] == 0, argv
+        pc.destroy()
+
+
 def test_setup_failure_with_one_oras_block_joins_the_hierarchy_thread(lib):
     """one subdomain per rank + ORAS + AMG local solves: the level-1 hierarchy thread reads the Robin matrix; an
     eigensolve that fails (here: a block narrower than -geneo_cut, refused before the first iteration) must come back as an error code with that thread joined
