@@ -2113,9 +2113,10 @@ int PC::lobpcg_solve(const EigProblem& P, int m, std::vector<double>& lam, doubl
       continue;
     }
     // it 0 runs direct (first calls size scratch buffers); while bench.py's in-situ kernel timer is on every 8th
-    // iteration runs direct so that its launches can be bracketed by events (graph nodes cannot)
+    // iteration (and the 4th: a solve that started from coarse Ritz vectors has only a handful) runs direct so that its
+    // launches can be bracketed by events (graph nodes cannot)
     const int par = it & 1;
-    const bool direct = no_graph || !reduced || (fused_update && !have_R) || (bk::spmv_profiling() && it % 8 == 1);
+    const bool direct = no_graph || !reduced || (fused_update && !have_R) || (bk::spmv_profiling() && (it % 8 == 1 || it == 4));
     if (!direct && !it_graph[par] && !it_graph_failed) {
       const int spmm_before = info.eig_spmm;
       if (bk::graph_capture_begin()) {
