@@ -2479,7 +2479,7 @@ int PC::eigen_lobpcg() {
   // Ritz vectors (rows of level l x m) of the pencil (A_l, Bl) for l >= 1; nullptr on failure.  Bl is borrowed.
   std::function<double*(int, const bk::Csr&)> level_vectors = [&](int l, const bk::Csr& Bl) -> double* {
     // (read per set-up: tests lower the row bound to reach the nested form on small grids)
-    const int min_rows = getenv("GENEO_COARSE_START_MIN_ROWS") ? atoi(getenv("GENEO_COARSE_START_MIN_ROWS")) : 20000;
+    const int min_rows = getenv("GENEO_COARSE_START_MIN_ROWS") ? atoi(getenv("GENEO_COARSE_START_MIN_ROWS")) : 4096;
     const double ctol = getenv("GENEO_COARSE_START_TOL") ? atof(getenv("GENEO_COARSE_START_TOL")) : 1e-2;
     const std::vector<int>& so = amgN->level_suboff(l);
     const int nl = amgN->level_rows(l);
