@@ -2476,92 +2476,84 @@ int PC::eigen_lobpcg() {
   // -geneo_cut) or a coarse solve did not deliver m independent pairs per subdomain -- the fine solve then starts from
   // its seeded random block as before.
   info.eig_coarse_iterations = 0;
-  // Ritz vectors (rows of level l x m) of the pencil (A_l, Bl) for l >= 1; nullptr on failure.  Bl is borrowed.
-  std::function<double*(int, const bk::Csr&)> level_vectors = [&](int l, const bk::Csr& Bl) -> double* {
+  // Start block of level l (rows of that level x m, device; the caller frees it) from the pencil of level l + 1:
+  // B_{l+1} = R_l Bl P_l, LOBPCG on (A_{l+1}, B_{l+1}) -- started the same way from level l + 2 -- and the prolonged Ritz
+  // vectors.  nullptr: level l + 1 is too small for the block, a product exceeded the kernels' capacity, or the solve did
+  // not deliver m independent pairs per subdomain.  Bl is borrowed.  Everything made here is released on every way out.
+  struct DevBlock {
+    double* p = nullptr;
+    ~DevBlock() { if (p) bk::dfree(p); }
+    double* release() { double* q = p; p = nullptr; return q; }
+  };
+  struct CsrHold {
+    bk::Csr c;
+    bool live = false;
+    void drop() { if (live) bk::csr_free(c); live = false; }
+    ~CsrHold() { drop(); }
+  };
+  struct ChunksHold {
+    bk::Chunks c;
+    ~ChunksHold() { if (c.start) bk::chunks_free(c); }
+  };
+  std::function<double*(int, const bk::Csr&)> start_block = [&](int l, const bk::Csr& Bl) -> double* {
+    if (l + 1 >= amgN->nlevels()) return nullptr;
     // (read per set-up: tests lower the row bound to reach the nested form on small grids)
     const int min_rows = getenv("GENEO_COARSE_START_MIN_ROWS") ? atoi(getenv("GENEO_COARSE_START_MIN_ROWS")) : 4096;
     const double ctol = getenv("GENEO_COARSE_START_TOL") ? atof(getenv("GENEO_COARSE_START_TOL")) : 1e-2;
-    const std::vector<int>& so = amgN->level_suboff(l);
-    const int nl = amgN->level_rows(l);
+    const std::vector<int>& co = amgN->level_suboff(l + 1);
+    const int nc = amgN->level_rows(l + 1);
+    // the level must carry the block comfortably in every subdomain; below level 1 also a minimum of rows on average
+    bool fits = (int)co.size() == ns + 1 && (l == 0 || (int64_t)nc >= (int64_t)min_rows * ns);
+    for (int s = 0; fits && s < ns; ++s) fits = co[s + 1] - co[s] >= 4 * m;
+    if (!fits) return nullptr;
     const auto t0 = clk::now();
-    double* X0 = nullptr;
-    if (l + 1 < amgN->nlevels()) {        // one level further down first, if it still carries the block comfortably
-      const std::vector<int>& co = amgN->level_suboff(l + 1);
-      bool deeper = (int)co.size() == ns + 1 && (int64_t)amgN->level_rows(l + 1) >= (int64_t)min_rows * ns;
-      for (int s = 0; deeper && s < ns; ++s) deeper = co[s + 1] - co[s] >= 4 * m;
-      if (deeper) {
-        const int nc = amgN->level_rows(l + 1);
-        bool ok = true;
-        bk::Csr BP = bk::spgemm(Bl, amgN->level_P(l), nc, &ok);
-        if (ok) {
-          bk::Csr Bc = bk::spgemm(amgN->level_R(l), BP, nc, &ok);
-          bk::csr_free(BP);
-          if (ok) {
-            bk::csr_finish(Bc);
-            double* Xc = level_vectors(l + 1, Bc);
-            if (Xc) {
-              X0 = dv((size_t)nl * m);
-              bk::spmm_strided(amgN->level_P(l), Xc, m, X0, m, m, nullptr, nullptr);
-              bk::dfree(Xc);
-            }
-            bk::csr_free(Bc);
-          }
-        }
-      }
-    }
+    CsrHold BP, Bc;
+    bool ok = true;
+    BP.c = bk::spgemm(Bl, amgN->level_P(l), nc, &ok);
+    BP.live = ok;
+    if (!ok) return nullptr;
+    Bc.c = bk::spgemm(amgN->level_R(l), BP.c, nc, &ok);
+    Bc.live = ok;
+    BP.drop();
+    if (!ok) return nullptr;
+    bk::csr_finish(Bc.c);
+    DevBlock below, Xc, X0;
+    below.p = start_block(l + 1, Bc.c);
     const auto t1 = clk::now();
-    bk::Chunks cc = bk::chunks_upload(ns, so.data());
-    EigProblem pc{&amgN->level_A(l), nullptr, &Bl, nullptr, amgN, amgN->level_dinv(l), cheb_lmax, nev_try, "tau-coarse"};
-    pc.rows = nl;
-    pc.chunks = &cc;
-    pc.row_off = so.data();
-    pc.amg_level = l;
+    ChunksHold cc;
+    cc.c = bk::chunks_upload(ns, co.data());
+    EigProblem pc{&amgN->level_A(l + 1), nullptr, &Bc.c, nullptr, amgN, amgN->level_dinv(l + 1), cheb_lmax, nev_try, "tau-coarse"};
+    pc.rows = nc;
+    pc.chunks = &cc.c;
+    pc.row_off = co.data();
+    pc.amg_level = l + 1;
     pc.tol = std::max(opt.eps_tol, ctol);     // a start block: the discretisation gap between two levels is larger than this
     pc.iterations = &info.eig_coarse_iterations;
     pc.max_it = 40;
-    pc.X0 = X0;
+    pc.X0 = below.p;
     std::vector<double> lamc;
-    double* Xl = dv((size_t)nl * m);
+    Xc.p = dv((size_t)nc * m);
     const int before = info.eig_coarse_iterations;
-    const int rc = lobpcg_solve(pc, m, lamc, Xl);
+    const int rc = lobpcg_solve(pc, m, lamc, Xc.p);
+    if (rc) last_error.clear();               // the coarse attempt is optional: its failure is not the set-up's
     bool full = rc == 0;
     for (size_t e = 0; full && e < lamc.size(); ++e) full = lamc[e] < 1e299;
-    if (rc) last_error.clear();               // the coarse attempt is optional: its failure is not the set-up's
-    if (X0) bk::dfree(X0);
-    bk::chunks_free(cc);
-    if (!full) { bk::dfree(Xl); Xl = nullptr; }
+    if (full) {
+      X0.p = dv((size_t)amgN->level_rows(l) * m);
+      bk::spmm_strided(amgN->level_P(l), Xc.p, m, X0.p, m, m, nullptr, nullptr);
+    }
     if (getenv("GENEO_DEBUG")) {
       bk::sync();
-      fprintf(stderr, "[coarse start] level %d: %d rows, levels below + B products %.3f s, %d LOBPCG iterations %.3f s%s\n", l, nl,
-              secs(t0, t1), info.eig_coarse_iterations - before, secs(t1, clk::now()), full ? "" : " -- not used");
+      fprintf(stderr, "[coarse start] level %d: %d rows, B products + levels below %.3f s, %d LOBPCG iterations + prolongation %.3f s%s\n",
+              l + 1, nc, secs(t0, t1), info.eig_coarse_iterations - before, secs(t1, clk::now()), full ? "" : " -- not used");
     }
-    return Xl;
+    return X0.release();
   };
   auto coarse_start = [&]() -> double* {
     if (g2 || !amgN || opt.els2_pc != "amg" || opt.eig_coarse_start <= 0 || ns == 0) return nullptr;
     if (!(opt.cut > 0 || opt.noSyl || opt.eps_block > 0)) return nullptr;
-    if ((int64_t)nL < (int64_t)opt.eig_coarse_start * ns || amgN->nlevels() < 2) return nullptr;
-    const std::vector<int>& co = amgN->level_suboff(1);
-    if ((int)co.size() != ns + 1) return nullptr;
-    for (int s = 0; s < ns; ++s)
-      if (co[s + 1] - co[s] < 4 * m) return nullptr;
-    const int nc = amgN->level_rows(1);
-    bool ok = true;
-    bk::Csr BP = bk::spgemm(dirBD, amgN->level_P(0), nc, &ok);
-    if (!ok) return nullptr;
-    bk::Csr Bc = bk::spgemm(amgN->level_R(0), BP, nc, &ok);
-    bk::csr_free(BP);
-    if (!ok) return nullptr;
-    bk::csr_finish(Bc);
-    double* X0 = nullptr;
-    double* Xc = level_vectors(1, Bc);
-    if (Xc) {
-      X0 = dv((size_t)nL * m);
-      bk::spmm_strided(amgN->level_P(0), Xc, m, X0, m, m, nullptr, nullptr);
-      bk::dfree(Xc);
-    }
-    bk::csr_free(Bc);
-    return X0;
+    if ((int64_t)nL < (int64_t)opt.eig_coarse_start * ns || amgN->level_rows(0) != nL) return nullptr;
+    return start_block(0, dirBD);
   };
   std::vector<Stage> stT, stG;
   auto release_all = [&]() {
