@@ -37,6 +37,8 @@ import subprocess
 import sys
 import time
 
+T_PROCESS0 = time.perf_counter()     # bench_wall_s in the JSON line: this process from here to the print (imports included)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -474,6 +476,7 @@ def one_rank_of(args):
                               "coarse_Einv": info["lvl2ApplyEinvTimeLoc"]},
         "roofline": roof,
     }
+    out["bench_wall_s"] = round(time.perf_counter() - T_PROCESS0, 1)
     print(json.dumps(out), flush=True)
     pc.destroy()
 
@@ -902,6 +905,7 @@ def main():
                 out["one_gpu_anchor"] = one_gpu_anchor(args, lib, torch)
             except Exception as e:
                 out["one_gpu_anchor"] = {"error": repr(e)}
+        out["bench_wall_s"] = round(time.perf_counter() - T_PROCESS0, 1)   # everything this process did: imports, host preparation, CPU legs, all steps
         print(json.dumps(out), flush=True)
     if comm is not None and hasattr(comm, "close"):
         comm.close()
