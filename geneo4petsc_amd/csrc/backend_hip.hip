@@ -639,7 +639,8 @@ Csr csr_upload(int n, const int* h_rowptr, const int* h_col, const double* h_val
 // of the origin only rotates the strips).  Empty when less than 80 % of the slices lie in runs of three planes or more
 // (irregular matrices: the blobs stay).
 static std::vector<int> strip_schedule(int nslice, const std::vector<int>& frow) {
-  static const int WT = getenv("GENEO_SPMM_STRIP") ? atoi(getenv("GENEO_SPMM_STRIP")) : 3072;   // rows of a strip (target)
+  // rows of a strip (target); read per matrix, as the tile below: tests lower both to reach the schedules on small grids
+  const int WT = std::max(64, getenv("GENEO_SPMM_STRIP") ? atoi(getenv("GENEO_SPMM_STRIP")) : 3072);
   std::vector<int> order;
   order.reserve(nslice);
   int64_t covered = 0;
@@ -669,8 +670,8 @@ static std::vector<int> strip_schedule(int nslice, const std::vector<int>& frow)
 }
 
 static std::vector<int> blob_schedule(int n, const int* h_rowptr, const int* h_col, int nslice) {
-  static const int TILE = getenv("GENEO_SPMM_TILE") ? atoi(getenv("GENEO_SPMM_TILE")) : 512;
-  static const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto)
+  const int TILE = std::max(4, getenv("GENEO_SPMM_TILE") ? atoi(getenv("GENEO_SPMM_TILE")) : 512);
+  const char* mode = getenv("GENEO_SPMM_SCHED");   // natural | blob | (auto: strips, else blobs, else natural)
   if (mode && !strcmp(mode, "natural")) return {};
   if (nslice < 4 * TILE) return {};
   // Sampling: 4 rows per slice, two dependent cache misses each (row pointer, columns) -- latency-bound on one host thread

@@ -109,6 +109,46 @@ def test_spmm(lib, m):
                                atol=1e-13)
 
 
+def test_spmm_slice_schedules_natural_blobs_strips(lib, monkeypatch, capfd):
+    """Traversal order of the sliced SpMM (backend_hip.hip: blob_schedule / strip_schedule): compact blobs of the slice graph,
+    or -- one far offset per block, a 3-D stencil in natural order -- strips of a grid plane walked through all planes.  A
+    schedule is a permutation of the slices and nothing else: the products of the natural order, bit for bit, for two
+    blocks of different plane sizes in one flat matrix (two runs of equal far offset).  The tile and strip sizes are lowered
+    so that a 40 x 40 x 36 and a 32 x 32 x 40 block reach the schedules the 187^3 blocks of the benchmark take."""
+    from geneo4petsc_amd.pc import Spmv
+
+    def stencil(nx, ny, nz, seed):
+        def t(k):
+            e = np.ones(k)
+            return sp.diags([e[:-1], e, e[:-1]], [-1, 0, 1])
+        a = (sp.kron(sp.kron(sp.identity(nz), sp.identity(ny)), t(nx)) + sp.kron(sp.kron(sp.identity(nz), t(ny)), sp.identity(nx))
+             + sp.kron(sp.kron(t(nz), sp.identity(ny)), sp.identity(nx))).tocsr()
+        a.sort_indices()
+        a.data = np.random.default_rng(seed).random(a.nnz) - 0.5
+        return a
+    a = sp.block_diag([stencil(40, 40, 36, 1), stencil(32, 32, 40, 2)], format="csr")
+    a.sort_indices()
+    n = a.shape[0]
+    X = np.random.default_rng(3).random((n, 32)) - 0.5
+    monkeypatch.setenv("GENEO_SPMM_TILE", "16")
+    monkeypatch.setenv("GENEO_SPMM_STRIP", "256")
+    monkeypatch.setenv("GENEO_DEBUG_SCHED", "1")
+    out = {}
+    for mode in ("natural", "blob", "strip"):
+        if mode == "strip":
+            monkeypatch.delenv("GENEO_SPMM_SCHED", raising=False)      # auto: strips where one far offset is found
+        else:
+            monkeypatch.setenv("GENEO_SPMM_SCHED", mode)
+        capfd.readouterr()
+        h = Spmv(a, lib)
+        out[mode] = h.spmm(X)
+        err = capfd.readouterr().err
+        assert ("[sched] strip" in err) == (mode == "strip"), (mode, err[-300:])
+    np.testing.assert_allclose(out["natural"], a @ X, rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(out["blob"], out["natural"])
+    np.testing.assert_array_equal(out["strip"], out["natural"])
+
+
 @pytest.mark.parametrize("density", [0.002, 0.012])
 @pytest.mark.parametrize("m", [1, 16, 32, 40])
 def test_fused_multigrid_epilogues(lib, m, density):
