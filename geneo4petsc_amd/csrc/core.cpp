@@ -1174,11 +1174,15 @@ void PC::local_solve(double* wL) {
       parity ^= 1;
     }
   };
+  // (a chunk's launches carry the rz parity it starts with: graphs are kept per (length, parity); odd lengths other than
+  // the single step of the tail below are not captured)
   auto graph_for = [&](int len) -> void* {
-    if (len % 2 != 0 || cg_graph_failed) return nullptr;
-    auto it_g = cg_graphs.find(len);
+    if ((len % 2 != 0 && len != 1) || cg_graph_failed) return nullptr;
+    const int key = 2 * len + parity;
+    auto it_g = cg_graphs.find(key);
     if (it_g != cg_graphs.end()) return it_g->second;
     void* g = nullptr;
+    const int parity_in = parity;
     if (bk::graph_capture_begin()) {
       try {
         chunk(len);
@@ -1188,10 +1192,10 @@ void PC::local_solve(double* wL) {
         throw;
       }
       g = bk::graph_capture_end();
-      parity = 0;
+      parity = parity_in;        // recorded, not run
     }
     if (!g) cg_graph_failed = true;
-    else cg_graphs[len] = g;
+    else cg_graphs[key] = g;
     return g;
   };
   static const bool dbg_dls1 = getenv("GENEO_DEBUG_DLS1") != nullptr;   // per solve: the chunk boundary each subdomain froze at
@@ -1203,8 +1207,12 @@ void PC::local_solve(double* wL) {
     // kernels inside a replayed graph (hipEventElapsedTime rejects events recorded by graph nodes), the other chunks
     // replay the graph as they do outside the benchmark.
     const bool direct = !g || (bk::spmv_profiling() && (cg_chunks++ % 8 == 0));
-    if (!direct) bk::graph_launch(g);
-    else chunk(len);
+    if (!direct) {
+      bk::graph_launch(g);
+      parity ^= (len & 1);
+    } else {
+      chunk(len);
+    }
     it += len;
     bk::d2h(sc.data(), d_cg_sc, sizeof(double) * 8 * ns);
     done = true;
@@ -1220,7 +1228,12 @@ void PC::local_solve(double* wL) {
   if (use_amg && adaptive && cg_long_len >= 8 && check % 2 == 0) {
     const int first = cg_long_len;
     run(first);
-    while (!done && it < opt.dls1_max_it) run(2);
+    // behind the long chunk: pairs of iterations, or -- where an iteration costs far more than the host round trip of a
+    // chunk boundary (4 M local rows and more: 0.5 ms and up against 0.17 ms) -- single ones, so that a solve stops at the
+    // iteration that converged it instead of the next even one
+    const int64_t single_rows = getenv("GENEO_DLS1_SINGLE_STEP_ROWS") ? atoll(getenv("GENEO_DLS1_SINGLE_STEP_ROWS")) : 4000000;   // (per solve: tests)
+    const int tail = (int64_t)nL >= single_rows ? 1 : 2;
+    while (!done && it < opt.dls1_max_it) run(tail);
     // The long chunk follows what the solves need.  The first solve of a set-up (the one the length was taken from) is the
     // hardest -- 368^3: 24 iterations, the others 16 -- and a chunk that ends after convergence is iterations nobody asked
     // for: at 5.6 ms each on 52 M rows, two of them per solve are 10 % of the solve.  Converged inside the long chunk: probe

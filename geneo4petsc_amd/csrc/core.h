@@ -209,7 +209,7 @@ class PC {
   int setup_finish(const double* b_dev);   // second half: level 2 and the bookkeeping
   std::vector<int> plan_eig_groups() const;
   int eigen_grouped();
-  std::map<int, void*> cg_graphs;   // HIP graphs of an inner-PCG chunk, by chunk length (local_solve)
+  std::map<int, void*> cg_graphs;   // HIP graphs of an inner-PCG chunk, by 2 * chunk length + rz parity at its start (local_solve)
   int cg_long_len = 0;         // length of the first chunk of a local solve once the first solve of this set-up is known (0: not yet, -1: never)
   bool cg_graph_failed = false;
   long long cg_chunks = 0;     // chunks issued so far (sampling of direct launches while the in-situ timer runs)

@@ -326,6 +326,26 @@ def test_cooperative_reductions_of_large_subdomains(lib, lvl, ksp, overlap):
     assert its == its_default and info["dimE"] == info_default["dimE"]
 
 
+def test_local_solves_single_step_tail(lib, monkeypatch):
+    """Inner PCG of the local solves: behind the long first chunk the iteration goes on in pairs, or -- large subdomains --
+    in single steps (HIP graphs per chunk length AND rz parity).  The row bound of the single steps is lowered so that a
+    40^3 case takes them: the same outer iteration count, the same solution to the inner tolerance, and never more inner
+    iterations than with pairs."""
+    mesh, dec, a, b = cases.grid_case(n=40, dim=3, parts=(2, 2, 2), overlap=2)
+    res = []
+    for rows in ("1000000000", "1"):
+        monkeypatch.setenv("GENEO_DLS1_SINGLE_STEP_ROWS", rows)
+        pc = cases.run_pc(lib, mesh, dec, cases.bench_argv(), b)
+        x, its, rnorm, reason = pc.solve(b)
+        res.append((x, its, reason, pc.info()["dls1_iterations"]))
+        pc.destroy()
+    (x2, its2, r2, inner2), (x1, its1, r1, inner1) = res
+    assert r1.startswith("KSP_CONVERGED") and its1 == its2
+    assert inner1 <= inner2, (inner1, inner2)
+    assert np.linalg.norm(x1 - x2) <= 1e-5 * np.linalg.norm(x2)
+    print("inner PCG iterations of the solve: %d in pairs, %d in single steps behind the long chunk" % (inner2, inner1))
+
+
 def test_eigensolve_coarse_start_nested(lib, monkeypatch, capfd):
     """VERDICT r3 item 8 (cut LOBPCG's iterations): -geneo_eig_coarse_start -- the fine eigensolve starts from the prolonged
     Ritz vectors of the level-1 Galerkin pencil, that solve from level 2 (nested iteration; the row bound of the nesting is
