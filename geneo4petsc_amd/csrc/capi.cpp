@@ -159,7 +159,7 @@ const char* usageGenEO_c(void) {
          "                   (1 = the reference's literal test; defaults to 100)\n"
          "  -geneo_eig_group_rows R / -geneo_eig_mem_gb G   memory-bounded set-up: eigensolve the rank's subdomains in\n"
          "                   consecutive groups of at most R local rows / G GiB of basis blocks (default: 35 % of the card)\n"
-         "  -geneo_eig_coarse_start R   subdomains of R rows or more on average: the local eigensolve starts from the Ritz\n"
+         "  -geneo_eig_coarse_start R   subdomains of R rows or more (all of a batch): the local eigensolve starts from the Ritz\n"
          "                   vectors of the multigrid level-1 pencil (itself started from level 2, ...) instead of a random\n"
          "                   block (default 750000; 0 = never)\n"
          "  -els2_eps_tol / -els2_eps_nev / -els2_eps_max_it / -els2_eps_block / -els2_pc_type amg|cheb\n"

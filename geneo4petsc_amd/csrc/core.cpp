@@ -2515,9 +2515,10 @@ int PC::eigen_lobpcg() {
     const double ctol = getenv("GENEO_COARSE_START_TOL") ? atof(getenv("GENEO_COARSE_START_TOL")) : 1e-2;
     const std::vector<int>& co = amgN->level_suboff(l + 1);
     const int nc = amgN->level_rows(l + 1);
-    // the level must carry the block comfortably in every subdomain; below level 1 also a minimum of rows on average
-    bool fits = (int)co.size() == ns + 1 && (l == 0 || (int64_t)nc >= (int64_t)min_rows * ns);
-    for (int s = 0; fits && s < ns; ++s) fits = co[s + 1] - co[s] >= 4 * m;
+    // the level must carry the block comfortably in EVERY subdomain of the batch (below level 1: min_rows of them), so that
+    // the choice does not depend on which subdomains share a batch as long as all of them qualify
+    bool fits = (int)co.size() == ns + 1;
+    for (int s = 0; fits && s < ns; ++s) fits = co[s + 1] - co[s] >= std::max(4 * m, l == 0 ? 0 : min_rows);
     if (!fits) return nullptr;
     const auto t0 = clk::now();
     CsrHold BP, Bc;
@@ -2565,7 +2566,9 @@ int PC::eigen_lobpcg() {
   auto coarse_start = [&]() -> double* {
     if (g2 || !amgN || opt.els2_pc != "amg" || opt.eig_coarse_start <= 0 || ns == 0) return nullptr;
     if (!(opt.cut > 0 || opt.noSyl || opt.eps_block > 0)) return nullptr;
-    if ((int64_t)nL < (int64_t)opt.eig_coarse_start * ns || amgN->level_rows(0) != nL) return nullptr;
+    if (amgN->level_rows(0) != nL) return nullptr;
+    for (int s = 0; s < ns; ++s)            // every subdomain of the batch at the threshold or above
+      if ((int64_t)subs[s].l2g.size() < (int64_t)opt.eig_coarse_start) return nullptr;
     return start_block(0, dirBD);
   };
   std::vector<Stage> stT, stG;

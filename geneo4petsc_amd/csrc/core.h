@@ -53,8 +53,8 @@ struct Options {
   //   eig_mem_gb     > 0: device-memory budget of one group's eigensolve in GiB;  0: 35 % of the card (unknown card: one group)
   int eig_group_rows = 0;
   double eig_mem_gb = 0.0;
-  // Coarse start of the local eigensolves (-geneo_eig_coarse_start R): when the rank's subdomains hold at least R rows each
-  // on average, LOBPCG first runs on the Galerkin pencil of multigrid level 1 (A_c = P^T A_Neu P from the hierarchy,
+  // Coarse start of the local eigensolves (-geneo_eig_coarse_start R): when every subdomain of the batch (the rank's
+  // subdomains, or one group of the memory-bounded set-up) holds at least R rows, LOBPCG first runs on the Galerkin pencil of multigrid level 1 (A_c = P^T A_Neu P from the hierarchy,
   // B_c = P^T D A_Dir D P: two sparse products) and the fine iteration starts from the prolonged Ritz vectors instead of a
   // random block: an iteration there costs an eighth of a fine one and the fine solve is left with the last digits.  The
   // fine pairs meet the same convergence test either way.  0: never.
