@@ -316,6 +316,23 @@ def test_memory_bounded_setup_without_cut_and_with_the_chebyshev_eigensolver(lib
     assert np.array_equal(res[0][1], res[1][1])
 
 
+def test_local_solves_single_step_tail(lib, monkeypatch):
+    """inner PCG of the local solves behind its long first chunk: single iterations (large subdomains; the row bound is
+    lowered here) instead of pairs -- same outer count, same solution to the inner tolerance, never more inner iterations"""
+    mesh, dec, a, b = cases.grid_case(n=16, dim=3, parts=(2, 2, 2), overlap=2)
+    res = []
+    for rows in ("1000000000", "1"):
+        monkeypatch.setenv("GENEO_DLS1_SINGLE_STEP_ROWS", rows)
+        pc = cases.run_pc(lib, mesh, dec, cases.bench_argv(), b)
+        x, its, rnorm, reason = pc.solve(b)
+        res.append((x, its, reason, pc.info()["dls1_iterations"]))
+        pc.destroy()
+    (x2, its2, r2, inner2), (x1, its1, r1, inner1) = res
+    assert r1.startswith("KSP_CONVERGED") and its1 == its2
+    assert inner1 <= inner2, (inner1, inner2)
+    assert np.linalg.norm(x1 - x2) <= 1e-5 * np.linalg.norm(x2)
+
+
 def test_eigensolve_coarse_start_gives_the_same_eigenpairs(lib):
     """-geneo_eig_coarse_start 1: LOBPCG on the Galerkin pencil of multigrid level 1 (A_c from the A_Neu hierarchy,
     B_c = P^T D A_Dir D P), its Ritz vectors prolonged as the start block of the fine iteration.  At a tight tolerance
